@@ -1,0 +1,45 @@
+"""ctypes loader for the plain-C restatement (oracle/dgl_ref.c).  Test infrastructure."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libdglref.so")
+
+
+def build() -> str:
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return _LIB
+
+
+def load() -> ctypes.CDLL:
+    if not os.path.exists(_LIB):
+        build()
+    lib = ctypes.CDLL(_LIB)
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+    ci = ctypes.c_int
+    lib.dglref_dist_row.argtypes = [f32p, ci, ci, f32p]
+    lib.dglref_dist_col.argtypes = [f32p, ci, ci, f32p]
+    lib.dglref_aten_sum.argtypes = [f32p, ctypes.c_int64]
+    lib.dglref_aten_sum.restype = ctypes.c_float
+    lib.dglref_row_mean_std.argtypes = [f32p, ci, f32p, f32p]
+    lib.dglref_tsp_knn.argtypes = [f32p, ci, ci, u8p, ci, i32p]
+    lib.dglref_tsp_knn.restype = ci
+    lib.dglref_cvrp_knn.argtypes = [f32p, ci, ci, u8p, ci, ci, i32p, i32p, ctypes.POINTER(ci)]
+    lib.dglref_cvrp_knn.restype = ci
+    lib.dglref_step_features.argtypes = [f32p, ci, ci, ci, ci, f32p, f32p, f32p]
+    lib.dglref_direction.argtypes = [f32p, ci, ci, f32p, f32p]
+    lib.dglref_cvrp_apply.argtypes = [ci, ci, f32p, ctypes.POINTER(ctypes.c_float), u8p, ctypes.POINTER(ci)]
+    lib.dglref_cvrp_apply.restype = ci
+    lib.dglref_tsp_length.argtypes = [f32p, i32p, ci]
+    lib.dglref_tsp_length.restype = ctypes.c_double
+    lib.dglref_cvrp_length.argtypes = [f32p, i32p, i8p, ci]
+    lib.dglref_cvrp_length.restype = ctypes.c_double
+    return lib

@@ -1,0 +1,334 @@
+"""Generate golden vectors by importing the reference (runs ONLY in the build
+container, where /root/reference is mounted; nothing here travels to the GPU box
+except the .npz files it writes under tests/golden/).
+
+The reference is imported unmodified.  Harness-side shims (they change nothing in
+the reference): an empty ``torch_cluster`` module (its ``knn`` is imported but
+never called) and ``sys.path`` pointing at the checkout so ``TSP.*``, ``CVRP.*``,
+``utils.*`` resolve.  The CLI scripts of the reference do not run as shipped, so
+Model / Env / Beamsearch are driven directly, following the loops of
+TSP/TSPTester.py:145-199 and CVRP/CVRPTester.py:147-227.
+
+usage: python oracle/make_goldens.py [--out tests/golden] [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("DGL_REFERENCE", "/root/reference")
+
+
+def _import_reference():
+    import matplotlib
+    matplotlib.use("Agg")
+    stub = types.ModuleType("torch_cluster")
+    stub.knn = None
+    sys.modules.setdefault("torch_cluster", stub)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from TSP.TSPModel import TSPModel
+    from TSP.TSPEnv import TSPEnv
+    from CVRP.CVRPModel import CVRPModel
+    from CVRP.CVRPEnv import CVRPEnv
+    from utils.beamsearch import Beamsearch
+    return TSPModel, TSPEnv, CVRPModel, CVRPEnv, Beamsearch
+
+
+TSP_INFO = [True, True, True, False, True, True, False, False, False, False, False]
+CVRP_INFO = [True, True, True, False, True, True, False, False, False, False, False, False, False]
+
+
+def model_params(info):
+    return dict(mode="test", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3,
+                qkv_dim=16, head_num=8, ff_hidden_dim=512, append_information=info)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _pad(rows, width, fill, dtype):
+    """list of [R, w_i] arrays -> [steps, R, width]."""
+    out = np.full((len(rows), rows[0].shape[0], width), fill, dtype=dtype)
+    for i, r in enumerate(rows):
+        out[i, :, : r.shape[1]] = r
+    return out
+
+
+_SAVED = set()
+
+
+def _save_weights(model, problem, wseed, ckpt, out_dir):
+    """Weights live in their own file (shared by every case that uses them):
+    either the reference's own seeded initialisation or a checkpoint in the
+    reference's format ({'model_state_dict': ...})."""
+    if ckpt:
+        load_checkpoint_into(model, ckpt)
+        wname = "weights_" + os.path.splitext(os.path.basename(ckpt))[0]
+    else:
+        wname = f"weights_{problem.lower()}_init{wseed}"
+    if wname not in _SAVED:
+        np.savez_compressed(os.path.join(out_dir, wname + ".npz"),
+                            **{k: _np(v) for k, v in model.state_dict().items()})
+        _SAVED.add(wname)
+    return wname
+
+
+def load_checkpoint_into(model, path):
+    import torch
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    model.load_state_dict(ck["model_state_dict"])
+
+
+def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None, out_dir=".",
+            wseed=789):
+    import torch
+    TSPModel, TSPEnv, _, _, Beamsearch = _import_reference()
+    torch.manual_seed(wseed)
+    model = TSPModel(**model_params(TSP_INFO))
+    wname = _save_weights(model, "TSP", wseed, ckpt, out_dir)
+    model.eval()
+    model.mode = "test"
+    torch.manual_seed(seed)
+    xy = torch.rand(B, N, 2)
+    start = torch.randperm(N)[:pomo]
+
+    env = TSPEnv(data_path="", baseline_path="", mode="test", test_mode="pomo_test", aug_size=pomo,
+                 append_information=TSP_INFO, aggregation_nums=50, pomo_size=1)
+    env.raw_data_nodes = xy
+    env.load_problems(0, B, N, beam)
+    env.start_idx = 0
+    env.step_size = B
+
+    rec = {"idx": [], "logits": [], "tile": [], "p": [], "scores": [], "prev_k": [], "action": [],
+           "tie": []}
+    snaps = {}
+
+    # harness-side taps (forward hooks / wrapping a bound method; reference code untouched)
+    orig_knn = model.get_knn_state
+
+    def tap_knn(state, sel, k):
+        knn_node, idx = orig_knn(state, sel, k)
+        rec["idx"].append(_np(idx).astype(np.int32))
+        # tie flag: is the k-th key equal to the (k+1)-th?  recomputed from the same inputs
+        R = state.data.shape[0]
+        last = sel[:, -1]
+        inst = torch.arange(R) // (R // model.batch_size)
+        key = model.dis_matrix[inst, last].clone()
+        key[torch.arange(R)[:, None], sel] += 1e2
+        srt = torch.sort(key, dim=1)[0]
+        kk = idx.shape[1]
+        tie = (srt[:, kk - 1] == srt[:, kk]) if kk < srt.shape[1] else torch.zeros(R, dtype=torch.bool)
+        rec["tie"].append(_np(tie))
+        return knn_node, idx
+
+    model.get_knn_state = tap_knn
+    model.encoder.register_forward_pre_hook(lambda m, a: rec["tile"].append(_np(a[0]).copy()))
+    model.decoder.Linear_final.register_forward_hook(
+        lambda m, a, o: rec["logits"].append(_np(o.squeeze(-1)).copy()))
+
+    with torch.no_grad():
+        bs = Beamsearch(beam, env.batch_size * env.pomo_size, N, torch.FloatTensor, torch.LongTensor,
+                        "logits", False)
+        env.reset("test")
+        avg0, std0 = _np(env.step_state.avg_unselect_distence), _np(env.step_state.std_dev_unselect_distence)
+        state, reward, done = env.pre_step()
+        model.pre_forward(env.dis_matrix, env.batch_size)
+        step = 0
+        while not done:
+            if step == 0:
+                sel = start.repeat(env.batch_size).repeat_interleave(env.beam_size).to(torch.int64)
+            else:
+                _, probs, _ = model(state, env.selected_node_list, None, knn, step)
+                idx = rec["idx"][-1]
+                pr = _np(probs)
+                rec["p"].append(np.take_along_axis(pr, idx.astype(np.int64), axis=1))
+                env.selected_node_list = bs.advance(
+                    torch.log(probs.view(env.batch_size * env.pomo_size, beam, -1)), env, knn, step)
+                sel = bs.next_nodes[-1].view(-1)
+                rec["scores"].append(_np(bs.scores).copy())
+                rec["prev_k"].append(_np(bs.prev_Ks[-1]).astype(np.int32))
+                rec["action"].append(_np(bs.next_nodes[-1]).astype(np.int32))
+            step += 1
+            state, reward, done = env.step(sel)
+            if step in snap_steps:
+                snaps[f"snap{step}/data"] = _np(env.step_state.data).copy()
+                snaps[f"snap{step}/avg"] = _np(env.step_state.avg_unselect_distence).copy()
+                snaps[f"snap{step}/std"] = _np(env.step_state.std_dev_unselect_distence).copy()
+
+    tour = _np(env.selected_node_list).astype(np.int32)
+    length = _np(reward)
+    out = {
+        "meta/problem": np.array("TSP"), "meta/seed": np.array(seed), "meta/knn": np.array(knn),
+        "meta/beam": np.array(beam), "meta/pomo": np.array(pomo),
+        "meta/torch": np.array(torch.__version__), "meta/cpu": np.array(torch.backends.cpu.get_cpu_capability()),
+        "xy": _np(xy), "start": _np(start).astype(np.int32), "tour": tour, "length": length,
+        "avg0": avg0, "std0": std0,
+        "idx": _pad(rec["idx"], knn, -1, np.int32), "tie": np.stack(rec["tie"]),
+        "logits": _pad(rec["logits"], knn + 1, np.nan, np.float32),
+        "p": _pad(rec["p"], knn, np.nan, np.float32),
+    }
+    if beam > 1 or pomo > 1:
+        out["beam_scores"] = np.stack(rec["scores"])
+        out["beam_prev_k"] = np.stack(rec["prev_k"])
+        out["beam_action"] = np.stack(rec["action"])
+    if full:
+        out["tile"] = _pad([t.reshape(t.shape[0], -1) for t in rec["tile"]], (knn + 1) * 7, np.nan, np.float32)
+    out.update(snaps)
+    out["meta/weights"] = np.array(wname)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: tour {tour.shape} mean length {length.mean():.5f} ties {int(out['tie'].sum())} "
+          f"-> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None,
+             out_dir=".", wseed=789):
+    import torch
+    _, _, CVRPModel, CVRPEnv, Beamsearch = _import_reference()
+    torch.manual_seed(wseed)
+    model = CVRPModel(**model_params(CVRP_INFO))
+    wname = _save_weights(model, "CVRP", wseed, ckpt, out_dir)
+    model.eval()
+    model.mode = "test"
+    torch.manual_seed(seed)
+    depot_xy = torch.rand(B, 2)
+    node_xy = torch.rand(B, N, 2)
+    demand = torch.randint(1, 200, size=(B, N)) / 500.0      # CVRP/CVRPEnv.py:42-48 (N not in {20,50})
+    start = torch.randperm(N)[:pomo]
+
+    env = CVRPEnv(mode="test", test_mode="pomo_test", aug_size=pomo, append_information=CVRP_INFO,
+                  aggregation_nums=10, pomo_size=1)
+    env.raw_depot_node_xy, env.raw_node_xy, env.raw_node_demand = depot_xy, node_xy, demand
+    env.beam_size = beam
+    env.problem_size = N
+    env.load_problems(0, B, N)
+    env.start_idx = 0
+    env.step_size = B
+
+    rec = {"idx_last": [], "idx_dep": [], "logits": [], "tile": [], "p": [], "scores": [], "prev_k": [],
+           "action": [], "capacity": [], "ntok": []}
+    snaps = {}
+    orig_knn = model.get_knn_state
+
+    def tap_knn(state, sel, k, kd):
+        res = orig_knn(state, sel, k, kd)
+        rec["idx_last"].append(_np(res[2]).astype(np.int32))
+        rec["idx_dep"].append(_np(res[3]).astype(np.int32))
+        return res
+
+    model.get_knn_state = tap_knn
+    model.encoder.register_forward_pre_hook(lambda m, a: rec["tile"].append(_np(a[0]).copy()))
+    model.decoder.Linear_final.register_forward_hook(
+        lambda m, a, o: rec["logits"].append(_np(o.squeeze(-1)).copy()))
+
+    A = 2 * (N + 1)
+    with torch.no_grad():
+        bs = Beamsearch(beam, env.batch_size * env.pomo_size, N + 1, torch.FloatTensor, torch.LongTensor,
+                        "logits", False, "CVRP")
+        env.reset("test")
+        avg0, std0 = _np(env.step_state.avg_unselect_distence), _np(env.step_state.std_dev_unselect_distence)
+        state, reward, done = env.pre_step()
+        model.pre_forward(env.dis_matrix, env.batch_size)
+        step = 0
+        while not done:
+            if step == 0:
+                r = start.repeat(env.batch_size).repeat_interleave(env.beam_size)
+                sel = r.to(torch.int64) + 2 + N
+            else:
+                _, probs, _ = model(state, env.selected_node_list, None, None, knn, step, depot_knn,
+                                    env.step_state.selected_flag)
+                pr = _np(probs)
+                il, idp = rec["idx_last"][-1].astype(np.int64), rec["idx_dep"][-1].astype(np.int64)
+                rec["p"].append(np.concatenate((np.take_along_axis(pr, il, 1),
+                                                np.take_along_axis(pr, idp + N + 1, 1)), axis=1))
+                rec["capacity"].append(_np(env.step_state.capacity).copy())
+                env.selected_node_list = bs.advance(
+                    torch.log(probs.view(env.batch_size * env.pomo_size, beam, -1)), env, knn, step)
+                sel = bs.next_nodes[-1].view(-1)
+                rec["scores"].append(_np(bs.scores).copy())
+                rec["prev_k"].append(_np(bs.prev_Ks[-1]).astype(np.int32))
+                rec["action"].append(_np(bs.next_nodes[-1]).astype(np.int32))
+            step += 1
+            state, reward, done = env.step(sel.clone())
+            if step in snap_steps:
+                snaps[f"snap{step}/data"] = _np(env.step_state.data).copy()
+                snaps[f"snap{step}/avg"] = _np(env.step_state.avg_unselect_distence).copy()
+                snaps[f"snap{step}/std"] = _np(env.step_state.std_dev_unselect_distence).copy()
+                snaps[f"snap{step}/capacity"] = _np(env.step_state.capacity).copy()
+                snaps[f"snap{step}/ninf"] = _np(env.step_state.ninf_mask).copy()
+
+    nodes = _np(env.selected_node_list).astype(np.int32)
+    flags = _np(env.step_state.selected_flag).astype(np.int8)
+    length = _np(reward)
+    ntok = knn + 1 + depot_knn + 1
+    out = {
+        "meta/problem": np.array("CVRP"), "meta/seed": np.array(seed), "meta/knn": np.array(knn),
+        "meta/depot_knn": np.array(depot_knn), "meta/beam": np.array(beam), "meta/pomo": np.array(pomo),
+        "meta/torch": np.array(torch.__version__), "meta/cpu": np.array(torch.backends.cpu.get_cpu_capability()),
+        "depot_xy": _np(depot_xy), "node_xy": _np(node_xy), "demand": _np(demand),
+        "start": _np(start).astype(np.int32), "nodes": nodes, "flags": flags, "length": length,
+        "avg0": avg0, "std0": std0,
+        "idx_last": _pad(rec["idx_last"], knn, -1, np.int32),
+        "idx_dep": _pad(rec["idx_dep"], depot_knn, -1, np.int32),
+        "logits": _pad(rec["logits"], ntok, np.nan, np.float32),
+        "p": _pad(rec["p"], knn + depot_knn, np.nan, np.float32),
+        "capacity": np.stack(rec["capacity"]),
+    }
+    if beam > 1 or pomo > 1:
+        out["beam_scores"] = np.stack(rec["scores"])
+        out["beam_prev_k"] = np.stack(rec["prev_k"])
+        out["beam_action"] = np.stack(rec["action"])
+    if full:
+        out["tile"] = _pad([t.reshape(t.shape[0], -1) for t in rec["tile"]], ntok * 9, np.nan, np.float32)
+    out.update(snaps)
+    out["meta/weights"] = np.array(wname)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: nodes {nodes.shape} mean length {length.mean():.5f} via-depot moves "
+          f"{int(flags.sum())} -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+CASES = {
+    # name: (fn, kwargs)
+    "tsp_n50_b4": ("tsp", dict(seed=789, B=4, N=50, knn=30, full=True, snap_steps=(1, 2, 3, 25, 49))),
+    "tsp_n100_b8": ("tsp", dict(seed=789, B=8, N=100, knn=30, snap_steps=(1, 2, 3, 50, 99))),
+    "tsp_n100_b8_s123": ("tsp", dict(seed=123, B=8, N=100, knn=30)),
+    "tsp_n1000_b2": ("tsp", dict(seed=789, B=2, N=1000, knn=30, snap_steps=(1, 500, 999))),
+    "tsp_n60_b2_beam4_pomo2": ("tsp", dict(seed=789, B=2, N=60, knn=30, beam=4, pomo=2)),
+    "tsp_n200_b1_beam16": ("tsp", dict(seed=123, B=1, N=200, knn=30, beam=16)),
+    "cvrp_n60_b4": ("cvrp", dict(seed=789, B=4, N=60, knn=15, depot_knn=15, full=True,
+                                 snap_steps=(1, 2, 3, 30, 59))),
+    "cvrp_n100_b8": ("cvrp", dict(seed=789, B=8, N=100, knn=15, depot_knn=15, snap_steps=(1, 2, 50, 99))),
+    "cvrp_n1000_b2": ("cvrp", dict(seed=123, B=2, N=1000, knn=15, depot_knn=15, snap_steps=(1, 500))),
+    "cvrp_n60_b2_beam4_pomo2": ("cvrp", dict(seed=789, B=2, N=60, knn=15, depot_knn=15, beam=4, pomo=2)),
+    "cvrp_n120_b2_k20": ("cvrp", dict(seed=5, B=2, N=120, knn=20, depot_knn=20)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--ckpt-tsp", default=None)
+    ap.add_argument("--ckpt-cvrp", default=None)
+    ap.add_argument("--suffix", default="")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name, (kind, kw) in CASES.items():
+        if args.only and args.only not in name:
+            continue
+        if kind == "tsp":
+            gen_tsp(name + args.suffix, out_dir=args.out, ckpt=args.ckpt_tsp, **kw)
+        else:
+            gen_cvrp(name + args.suffix, out_dir=args.out, ckpt=args.ckpt_cvrp, **kw)
+
+
+if __name__ == "__main__":
+    main()
