@@ -1,0 +1,281 @@
+// TSP environment state on the device: reset, fused step + neighbourhood + token tile,
+// dense state materialisation, tour length, beam permutation.
+//
+// Layout: one wave64 owns one row (one partial tour).  Coordinates are read from the
+// instance ([B][N][2], shared by the rows of an instance), the running features avg/sd
+// are [R][N] binary32, the visited set is a bitmask.  No [N][N] distance matrix and no
+// [R][N][7] feature tensor exist: distances are recomputed with the reference's exact
+// arithmetic wherever they are needed.
+#include "common.h"
+#include "select.h"
+
+#define TSP_F 7
+
+// --------------------------------------------------------------------------- reset
+// grid: (ceil(N / 4), B), block 256 = 4 waves, wave w handles node i = 4*blockIdx.x + w.
+// The instance's coordinates are staged once per block in LDS.
+__global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
+    extern __shared__ float lds_xy[];   // [N][2]
+    const int b = blockIdx.y, N = st.N;
+    const float *xyb = st.xy + (size_t)b * N * 2;
+    for (int e = threadIdx.x; e < 2 * N; e += blockDim.x) lds_xy[e] = xyb[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i < N) {
+        const float xi = lds_xy[2 * i], yi = lds_xy[2 * i + 1], ni = dgl_sqnorm(xi, yi);
+        double s = 0.0, q = 0.0;
+        for (int j = lane; j < N; j += 64) {
+            float xj = lds_xy[2 * j], yj = lds_xy[2 * j + 1];
+            double d = (double)dgl_chain_dist(xi, yi, ni, xj, yj, dgl_sqnorm(xj, yj));
+            s += d;
+            q = fma(d, d, q);
+        }
+        s = wave_sum_f64(s);
+        q = wave_sum_f64(q);
+        double mean = s / N;
+        double var = q / N - mean * mean;
+        float favg = (float)mean, fsd = (float)sqrt(var > 0.0 ? var : 0.0);
+        for (int p = lane; p < st.rows_per_instance; p += 64) {
+            size_t r = (size_t)b * st.rows_per_instance + p;
+            st.avg[r * N + i] = favg;
+            st.sd[r * N + i] = fsd;
+        }
+    }
+    // clear the visited words of this instance's rows (block x == 0 only)
+    if (blockIdx.x == 0) {
+        const int W = (N + 63) / 64;
+        size_t base = (size_t)b * st.rows_per_instance * W;
+        for (int e = threadIdx.x; e < st.rows_per_instance * W; e += blockDim.x) st.visited[base + e] = 0ull;
+    }
+}
+
+// ---------------------------------------------------------------------------- step
+// One wave per row.  LDS per wave: keys[N] + tile[(knn+1)*STRIDE] + scratch[64].
+struct TspRowCtx {
+    const float *xyb;
+    float xc, yc, nc, xs, ys, ns;
+    size_t rowN;
+};
+
+__device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
+    const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
+    const float ds = dgl_chain_dist(x, y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
+    const float den = __fadd_rn(ds, 1e-7f);
+    f[0] = x;
+    f[1] = y;
+    f[2] = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);                  // d(j, current)
+    f[3] = st.avg[cx.rowN + j];
+    f[4] = st.sd[cx.rowN + j];
+    f[5] = __fdiv_rn(__fsub_rn(cx.ys, y), den);
+    f[6] = __fdiv_rn(__fsub_rn(cx.xs, x), den);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
+                                                             int t, int knn, int32_t *__restrict__ idx_out,
+                                                             float *__restrict__ tile_out, int lds_per_wave) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * WAVES + wave;
+    if (r >= st.R) return;                                  // wave-uniform; no block barrier is used below
+    const int N = st.N, W = (N + 63) / 64;
+    float *keys = lds + (size_t)wave * lds_per_wave;
+    float *tile = keys + N;
+    float *scratch = tile + (knn + 1) * DGL_TILE_STRIDE;
+
+    const int b = r / st.rows_per_instance;
+    TspRowCtx cx;
+    cx.xyb = st.xy + (size_t)b * N * 2;
+    cx.rowN = (size_t)r * N;
+    const int cur = selected[r];
+    const int start = (t == 1) ? cur : st.tour[cx.rowN];
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
+
+    const int u = N - t;                                    // unvisited after this step
+    const float up1 = (float)(u + 1), uf = (float)u;
+    const bool want_knn = (idx_out != nullptr) && (t < N);
+    float lane_min = INFINITY;
+    uint64_t *vis = st.visited + (size_t)r * W;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long word = vis[j0 >> 6];      // same address for the whole wave
+        if (j < N) {
+            const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
+            const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);    // dis[j][cur]
+            const float a0 = st.avg[cx.rowN + j], s0 = st.sd[cx.rowN + j];
+            // TSP/TSPEnv.py:386, 408-409
+            const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);
+            const float e = __fsub_rn(dcol, a0);
+            const float s1 = sqrtf(__fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf));
+            st.avg[cx.rowN + j] = a1;
+            st.sd[cx.rowN + j] = s1;
+            if (want_knn) {
+                const float drow = dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
+                const bool visited = ((word >> (j & 63)) & 1ull) || (j == cur);
+                // the reference adds 1e2 to visited keys; they can never rank among the
+                // k <= #unvisited smallest, so they are simply excluded here
+                const float key = visited ? INFINITY : drow;
+                keys[j] = key;
+                lane_min = fminf(lane_min, key);
+            }
+        }
+    }
+    if (lane == 0) {
+        st.tour[cx.rowN + (t - 1)] = cur;
+        vis[cur >> 6] |= 1ull << (cur & 63);
+    }
+    if (!want_knn) return;
+
+    wave_lds_sync();
+    const int k = min(knn, u);
+    const float T = wave_kth_smallest(keys, N, k, lane_min, scratch);
+    int32_t *idx_row = idx_out + (size_t)r * knn;
+    wave_emit_selected(keys, N, k, T, [&](int j, int rank) {
+        idx_row[rank] = j;
+        tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+    });
+    for (int e = k + lane; e < knn; e += 64) idx_row[e] = -1;
+    // the lane that updated avg/sd of `cur` also reads them back (same-thread ordering)
+    if (lane == (cur & 63)) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+    wave_lds_sync();
+    float *tout = tile_out + (size_t)r * (knn + 1) * DGL_TILE_STRIDE;
+    wave_minmax_norm_store(tile, k + 1, TSP_F, DGL_TILE_STRIDE, tout);
+    // zero the padding columns so the policy kernel can load whole strides
+    for (int e = lane; e < (k + 1) * (DGL_TILE_STRIDE - TSP_F); e += 64) {
+        int tk = e / (DGL_TILE_STRIDE - TSP_F), c = TSP_F + e % (DGL_TILE_STRIDE - TSP_F);
+        tout[tk * DGL_TILE_STRIDE + c] = 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------- dense state (API parity)
+__global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restrict__ out) {
+    const int r = blockIdx.y;
+    const int N = st.N;
+    TspRowCtx cx;
+    cx.xyb = st.xy + (size_t)(r / st.rows_per_instance) * N * 2;
+    cx.rowN = (size_t)r * N;
+    const int cur = st.tour[cx.rowN + (t - 1)], start = st.tour[cx.rowN];
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
+        float f[TSP_F];
+        tsp_features(st, cx, j, f);
+        float *o = out + (cx.rowN + j) * TSP_F;
+#pragma unroll
+        for (int c = 0; c < TSP_F; ++c) o[c] = f[c];
+    }
+}
+
+// --------------------------------------------------------------------- tour length
+// one wave per row; segment = sqrt(fl(dx^2) + fl(dy^2)) as TSP/TSPEnv.py:559-560
+__global__ __launch_bounds__(256) void tsp_length_kernel(dgl_tsp_state_t st, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= st.R) return;
+    const int N = st.N;
+    const float *xyb = st.xy + (size_t)(r / st.rows_per_instance) * N * 2;
+    const int32_t *tour = st.tour + (size_t)r * N;
+    double s = 0.0;
+    for (int p = lane; p < N; p += 64) {
+        int a = tour[p], c = tour[p + 1 == N ? 0 : p + 1];
+        float dx = __fsub_rn(xyb[2 * a], xyb[2 * c]), dy = __fsub_rn(xyb[2 * a + 1], xyb[2 * c + 1]);
+        s += (double)sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) out[r] = (float)s;
+}
+
+// ------------------------------------------------------------------ beam permutation
+// dst row (g, b) <- src row (g, prev_k[g][b]); copies avg, sd, visited and the first t tour entries.
+__global__ __launch_bounds__(256) void tsp_permute_kernel(dgl_tsp_state_t src, dgl_tsp_state_t dst,
+                                                         const int32_t *__restrict__ prev_k, int beam, int t) {
+    const int r = blockIdx.x;
+    const int g = r / beam;
+    const int sr = g * beam + prev_k[r];
+    const int N = src.N, W = (N + 63) / 64;
+    const size_t so = (size_t)sr * N, d0 = (size_t)r * N;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        dst.avg[d0 + j] = src.avg[so + j];
+        dst.sd[d0 + j] = src.sd[so + j];
+        if (j < t) dst.tour[d0 + j] = src.tour[so + j];
+    }
+    for (int w = threadIdx.x; w < W; w += blockDim.x) dst.visited[(size_t)r * W + w] = src.visited[(size_t)sr * W + w];
+}
+
+// ------------------------------------------------------------------------ launchers
+static int check_tsp_state(const dgl_tsp_state_t *st) {
+    DGL_CHECK_ARG(st != nullptr, "state is NULL");
+    DGL_CHECK_ARG(st->B > 0 && st->N > 1 && st->rows_per_instance > 0, "bad sizes B=%d N=%d rows_per_instance=%d",
+                  st->B, st->N, st->rows_per_instance);
+    DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
+    DGL_CHECK_ARG(st->xy && st->avg && st->sd && st->visited && st->tour, "NULL state buffer");
+    return DGL_OK;
+}
+
+extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    size_t lds = (size_t)st->N * 2 * sizeof(float);
+    DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void *)tsp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((st->N + 3) / 4, st->B);
+    hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
+    DGL_CHECK_LAUNCH("dgl_tsp_reset");
+    return DGL_OK;
+}
+
+extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
+                            int32_t *idx_out, float *tile_out, dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    DGL_CHECK_ARG(selected != nullptr, "selected is NULL");
+    DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
+    DGL_CHECK_ARG((idx_out == nullptr) == (tile_out == nullptr), "idx_out and tile_out must both be given or both be NULL");
+    DGL_CHECK_ARG(idx_out == nullptr || knn >= 1, "knn=%d must be >= 1", knn);
+    if (idx_out == nullptr) knn = 1;
+    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 64;
+    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
+    if (lds4 <= 64 * 1024) {
+        hipLaunchKernelGGL(tsp_step_kernel<4>, dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream, *st,
+                           selected, t, knn, idx_out, tile_out, per_wave);
+    } else {
+        size_t lds1 = (size_t)per_wave * sizeof(float);
+        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
+        if (lds1 > 48 * 1024)
+            hipFuncSetAttribute((const void *)tsp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipLaunchKernelGGL(tsp_step_kernel<1>, dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, selected, t,
+                           knn, idx_out, tile_out, per_wave);
+    }
+    DGL_CHECK_LAUNCH("dgl_tsp_step");
+    return DGL_OK;
+}
+
+extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
+    DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
+    dim3 grid(min((st->N + 255) / 256, 64), st->R);
+    hipLaunchKernelGGL(tsp_state_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    DGL_CHECK_LAUNCH("dgl_tsp_state_data");
+    return DGL_OK;
+}
+
+extern "C" int dgl_tsp_tour_length(const dgl_tsp_state_t *st, float *length_out, dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    DGL_CHECK_ARG(length_out != nullptr, "length_out is NULL");
+    hipLaunchKernelGGL(tsp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
+    DGL_CHECK_LAUNCH("dgl_tsp_tour_length");
+    return DGL_OK;
+}
+
+extern "C" int dgl_tsp_permute(const dgl_tsp_state_t *src, const dgl_tsp_state_t *dst, const int32_t *prev_k,
+                               int32_t beam, int32_t t, dgl_stream_t stream) {
+    if (int e = check_tsp_state(src)) return e;
+    if (int e = check_tsp_state(dst)) return e;
+    DGL_CHECK_ARG(prev_k != nullptr && beam >= 1, "bad prev_k/beam");
+    DGL_CHECK_ARG(src->R == dst->R && src->N == dst->N && src->R % beam == 0, "src/dst shapes differ or R %% beam != 0");
+    DGL_CHECK_ARG(src->avg != dst->avg && src->sd != dst->sd && src->tour != dst->tour && src->visited != dst->visited,
+                  "src and dst must be distinct buffers");
+    hipLaunchKernelGGL(tsp_permute_kernel, dim3(src->R), dim3(256), 0, (hipStream_t)stream, *src, *dst, prev_k, beam, t);
+    DGL_CHECK_LAUNCH("dgl_tsp_permute");
+    return DGL_OK;
+}

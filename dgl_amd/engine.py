@@ -1,0 +1,158 @@
+"""Device-side engines: thin owners of the HBM buffers that the C-ABI kernels work on.
+
+PyTorch is used only to allocate device memory and to name the HIP stream; every
+computation on the decode path is a call into libdgl_amd.so.  The reference-facing
+classes (dgl_amd.tsp / dgl_amd.cvrp / dgl_amd.beamsearch) sit on top of these.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import PROBLEM_CVRP, PROBLEM_TSP, MAX_TOKENS, TILE_STRIDE, check, ptr, stream_ptr
+
+_BLOCKS = ["encoder.layers.0.", "decoder.layers.0.", "decoder.layers.1.", "decoder.layers.2."]
+
+
+class PackedPolicy:
+    """Weights of TSPModel / CVRPModel re-laid out for the MFMA kernel.
+
+    ``state_dict`` uses the reference's checkpoint keys (TSP/TSPModel.py:238-339,
+    CVRP/CVRPModel.py:378-427)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], problem: int, device: torch.device):
+        self.problem = problem
+        self.device = device
+        lib = _lib.load()
+        sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()}
+        feat = 7 if problem == PROBLEM_TSP else 9
+        if tuple(sd["encoder.embedding.weight"].shape) != (128, feat):
+            raise ValueError(f"encoder.embedding.weight has shape {tuple(sd['encoder.embedding.weight'].shape)}, "
+                             f"expected (128, {feat})")
+        w = _lib.PolicyWeights()
+        w.problem = problem
+        w.emb_w, w.emb_b = ptr(sd["encoder.embedding.weight"]), ptr(sd["encoder.embedding.bias"])
+        for i, pre in enumerate(_BLOCKS):
+            b = w.block[i]
+            b.wq, b.wk, b.wv = ptr(sd[pre + "Wq.weight"]), ptr(sd[pre + "Wk.weight"]), ptr(sd[pre + "Wv.weight"])
+            b.wc, b.bc = ptr(sd[pre + "multi_head_combine.weight"]), ptr(sd[pre + "multi_head_combine.bias"])
+            b.w1, b.b1 = ptr(sd[pre + "feedForward.W1.weight"]), ptr(sd[pre + "feedForward.W1.bias"])
+            b.w2, b.b2 = ptr(sd[pre + "feedForward.W2.weight"]), ptr(sd[pre + "feedForward.W2.bias"])
+        if problem == PROBLEM_TSP:
+            names = ["decoder.embedding_last_node", "decoder.embedding_last_node"]
+        else:
+            names = ["decoder.embedding_last_node_not_via_depot", "decoder.embedding_last_node_via_depot"]
+        for a, nm in enumerate(names):
+            w.anchor_w[a], w.anchor_b[a] = ptr(sd[nm + ".weight"]), ptr(sd[nm + ".bias"])
+        w.final_w, w.final_b = ptr(sd["decoder.Linear_final.weight"]), ptr(sd["decoder.Linear_final.bias"])
+        self.packed = torch.empty(lib.dgl_policy_packed_floats(problem), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            check(lib.dgl_policy_pack(ctypes.byref(w), ptr(self.packed), stream_ptr()), "dgl_policy_pack")
+            torch.cuda.current_stream().synchronize()      # sd may be freed after this returns
+
+
+class TspEngine:
+    """Compact TSP state for R = B * rows_per_instance rows plus per-step scratch."""
+
+    def __init__(self, xy: torch.Tensor, rows_per_instance: int, knn: int):
+        assert xy.is_cuda and xy.dtype == torch.float32 and xy.dim() == 3 and xy.shape[2] == 2
+        self.lib = _lib.load()
+        self.xy = xy.contiguous()
+        self.B, self.N = xy.shape[0], xy.shape[1]
+        self.rpi = rows_per_instance
+        self.R = self.B * rows_per_instance
+        self.knn = knn
+        dev = xy.device
+        self.device = dev
+        R, N = self.R, self.N
+        self.W = (N + 63) // 64
+        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]
+        self.cur = 0
+        self.idx = torch.empty(R, knn, dtype=torch.int32, device=dev)
+        self.tile = torch.zeros(R, (knn + 1) * TILE_STRIDE, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self.prob = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
+        self.length = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def _alloc_state(self):
+        R, N, dev = self.R, self.N, self.device
+        t = dict(avg=torch.empty(R, N, dtype=torch.float32, device=dev),
+                 sd=torch.empty(R, N, dtype=torch.float32, device=dev),
+                 visited=torch.zeros(R, self.W, dtype=torch.int64, device=dev),
+                 tour=torch.zeros(R, N, dtype=torch.int32, device=dev))
+        s = _lib.TspState(self.B, N, self.rpi, R, ptr(self.xy), ptr(t["avg"]), ptr(t["sd"]), ptr(t["visited"]),
+                          ptr(t["tour"]))
+        t["struct"] = s
+        return t
+
+    @property
+    def state(self):
+        return self.bufs[self.cur]
+
+    def reset(self) -> None:
+        check(self.lib.dgl_tsp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_tsp_reset")
+        self.t = 0
+
+    def step(self, selected: torch.Tensor, want_knn: bool = True) -> None:
+        """Apply ``selected`` (int32 [R]) and, unless the tour is complete, build the next neighbourhood."""
+        assert selected.dtype == torch.int32 and selected.is_cuda and selected.numel() == self.R
+        self.t += 1
+        more = want_knn and self.t < self.N
+        check(self.lib.dgl_tsp_step(ctypes.byref(self.state["struct"]), ptr(selected), self.t, self.knn,
+                                    ptr(self.idx) if more else 0, ptr(self.tile) if more else 0, stream_ptr()),
+              "dgl_tsp_step")
+
+    @property
+    def k(self) -> int:
+        return min(self.knn, self.N - self.t)
+
+    def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
+        k = self.k
+        return _lib.PolicyIO(PROBLEM_TSP, self.R, k + 1, k, self.N, self.knn, 0, (self.knn + 1) * TILE_STRIDE,
+                             ptr(self.tile), ptr(self.idx), 0, 0,
+                             ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
+                             ptr(self.selected) if want_selected else 0)
+
+    def forward(self, policy: PackedPolicy, **kw) -> None:
+        io = self.policy_io(**kw)
+        check(self.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+
+    def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.R, self.N, dtype=torch.float32, device=self.device)
+        io = self.policy_io()
+        check(self.lib.dgl_policy_scatter_probs(ctypes.byref(io), ptr(self.prob), ptr(out), self.N, stream_ptr()),
+              "dgl_policy_scatter_probs")
+        return out
+
+    def permute(self, prev_k: torch.Tensor, beam: int) -> None:
+        assert len(self.bufs) == 2 and prev_k.dtype == torch.int32
+        src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
+        check(self.lib.dgl_tsp_permute(ctypes.byref(src["struct"]), ctypes.byref(dst["struct"]), ptr(prev_k), beam,
+                                       self.t, stream_ptr()), "dgl_tsp_permute")
+        self.cur = 1 - self.cur
+
+    def data(self) -> torch.Tensor:
+        out = torch.empty(self.R, self.N, 7, dtype=torch.float32, device=self.device)
+        check(self.lib.dgl_tsp_state_data(ctypes.byref(self.state["struct"]), self.t, ptr(out), stream_ptr()),
+              "dgl_tsp_state_data")
+        return out
+
+    def tour_length(self) -> torch.Tensor:
+        check(self.lib.dgl_tsp_tour_length(ctypes.byref(self.state["struct"]), ptr(self.length), stream_ptr()),
+              "dgl_tsp_tour_length")
+        return self.length
+
+    def greedy_rollout(self, policy: PackedPolicy, start: torch.Tensor) -> torch.Tensor:
+        """Whole greedy decode (beam 1): N-1 policy decisions, everything stays on the device."""
+        self.reset()
+        self.step(start)
+        while self.t < self.N:
+            self.forward(policy, want_logits=False, want_prob=False)
+            self.step(self.selected)
+        return self.tour_length()

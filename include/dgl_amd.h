@@ -1,0 +1,233 @@
+/*
+ * dgl_amd.h - C ABI of the MI355X (gfx950) decode-step library for DGL
+ * (Dynamic Global-Local aggregation TSP/CVRP solver).
+ *
+ * The reference has no FFI of its own: its hot path is a Python object protocol
+ * (model.forward / env.step / Beamsearch.advance).  Each entry point below replaces
+ * the body of one or more of those methods; the file:line of the reference code it
+ * stands in for is given with each declaration (paths relative to the reference
+ * checkout).  The Python classes in dgl_amd/ that keep the reference's signatures are
+ * thin callers of these functions.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *  - nothing is allocated or freed inside any entry point;
+ *  - every call is asynchronous on the given HIP stream (a hipStream_t passed as
+ *    void*; NULL = the default stream) and re-entrant per stream;
+ *  - return value 0 = success, negative = error (see dgl_last_error_string());
+ *    no C++ exception crosses the boundary;
+ *  - rows: R = B * rows_per_instance; row r belongs to instance r / rows_per_instance
+ *    (rows_per_instance = pomo * beam, TSP/TSPEnv.py:230-232);
+ *  - node ids and positions are int32 on the device (the reference uses int64 on the
+ *    host side; the Python layer converts at the boundary);
+ *  - all floating point state is IEEE binary32; distances use the arithmetic of
+ *    torch.cdist's matrix-product path (see dgl_tsp_reset).
+ */
+#ifndef DGL_AMD_H
+#define DGL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGL_AMD_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define DGL_OK 0
+#define DGL_ERR_INVALID_ARGUMENT (-1)
+#define DGL_ERR_UNSUPPORTED (-2)
+#define DGL_ERR_LAUNCH (-3)
+
+#define DGL_TILE_STRIDE 12 /* floats per token in a feature tile (7 used for TSP, 9 for CVRP) */
+#define DGL_MAX_TOKENS 32  /* tokens per row handled by dgl_policy_forward */
+
+#if defined(__GNUC__)
+#define DGL_API __attribute__((visibility("default")))
+#else
+#define DGL_API
+#endif
+
+typedef void *dgl_stream_t;
+
+DGL_API int dgl_version(void);
+/* Thread-local, valid until the next failing call on the same thread. */
+DGL_API const char *dgl_last_error_string(void);
+
+/* ------------------------------------------------------------------ TSP state
+ * Compact per-row state that replaces the reference's Step_State
+ * (TSP/TSPEnv.py:39-43: data [R,N,7], avg/std [R,N]) and its dense dis_matrix
+ * [B,N,N] (TSP/TSPEnv.py:125,228).  Distances are recomputed from coordinates. */
+typedef struct {
+    int32_t B;                 /* instances */
+    int32_t N;                 /* nodes per instance */
+    int32_t rows_per_instance; /* pomo * beam */
+    int32_t R;                 /* B * rows_per_instance */
+    const float *xy;           /* [B][N][2] */
+    float *avg;                /* [R][N] running mean distance to the unvisited nodes */
+    float *sd;                 /* [R][N] running std of the same */
+    uint64_t *visited;         /* [R][ceil(N/64)] bit j of word j/64 set = node visited */
+    int32_t *tour;             /* [R][N] position -> node (the reference's selected_node_list) */
+} dgl_tsp_state_t;
+
+/* TSPEnv.reset('test') (TSP/TSPEnv.py:216-235) + load_problems' cdist (:125):
+ * avg[r][i] = mean_j d(i,j), sd[r][i] = population std_j d(i,j) for every row of the
+ * instance, visited cleared.  d(i,j) is the binary32 chain
+ *   n_i = fl(fl(x_i^2)+fl(y_i^2)); a = fl((-2x_i) x_j); a = fma(-2y_i, y_j, a);
+ *   a = fl(a + n_i); a = fl(a + n_j); d = sqrt(max(a,0))
+ * i.e. what torch.cdist computes for more than 25 points.  No [N,N] matrix is stored. */
+DGL_API int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream);
+
+/* TSPEnv.step (TSP/TSPEnv.py:318-516) fused with TSPModel.get_knn_state,_get_node,
+ * _norm_node (TSP/TSPModel.py:50-100,141-172).
+ *  selected[r]: node chosen for position t-1 (t = number of visited nodes AFTER this call).
+ *  Updates tour, visited, avg, sd (u = N - t unvisited).  If t < N and idx_out != NULL
+ *  also builds the next decision's neighbourhood: k = min(knn, N - t) nearest unvisited
+ *  nodes of `selected`, key = d(selected, j) (+100 for visited), lowest index wins ties,
+ *  idx_out[r][0..k) ascending (rest -1; row stride knn), and the min-max normalised
+ *  token tile tile_out[r][k+1][DGL_TILE_STRIDE]: tokens 0..k-1 = neighbours, token k =
+ *  the current node, columns x, y, d(j,cur), avg, sd, sin_to_start, cos_to_start. */
+DGL_API int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
+                 int32_t *idx_out, float *tile_out, dgl_stream_t stream);
+
+/* The reference's step_state.data [R][N][7] (TSP/TSPEnv.py:371,393,415,456,475),
+ * materialised from the compact state after t >= 1 steps; for API parity and tests. */
+DGL_API int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
+
+/* TSPEnv._get_travel_distance (TSP/TSPEnv.py:554-564): closed tour length per row,
+ * segments sqrt(fl(dx^2)+fl(dy^2)), accumulated in binary64, rounded once. */
+DGL_API int dgl_tsp_tour_length(const dgl_tsp_state_t *st, float *length_out, dgl_stream_t stream);
+
+/* ----------------------------------------------------------------- CVRP state
+ * Replaces CVRP/CVRPEnv.py:170-180 (Step_State) and the dense dis_matrix.
+ * Nodes 0..N, node 0 = depot; M = N + 1 points per instance. */
+typedef struct {
+    int32_t B;
+    int32_t N;                 /* customers; M = N + 1 nodes */
+    int32_t rows_per_instance;
+    int32_t R;
+    const float *xy;           /* [B][M][2] depot first */
+    const float *demand;       /* [B][M] demand / vehicle capacity, depot 0 */
+    float *avg;                /* [R][M] */
+    float *sd;                 /* [R][M] */
+    float *capacity;           /* [R] remaining capacity (starts at 1) */
+    uint64_t *visited;         /* [R][ceil(M/64)] */
+    int32_t *nodes;            /* [R][N] position -> customer */
+    int8_t *flags;             /* [R][N] 1 = reached via the depot */
+} dgl_cvrp_state_t;
+
+/* CVRPEnv.reset('test') (CVRP/CVRPEnv.py:456-482). */
+DGL_API int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream);
+
+/* CVRPEnv.step (CVRP/CVRPEnv.py:591-873) fused with CVRPModel.get_knn_state/_norm_node and
+ * the tile assembly of CVRPModel.forward (CVRP/CVRPModel.py:51-187,258-309).
+ *  action[r] in [0, 2(N+1)): node a, or node a-(N+1) via the depot.
+ *  kd' = min(depot_knn, N - t), kl = min(knn, kd').  idx_last_out[r][0..kl),
+ *  idx_depot_out[r][0..kd') ascending (row strides knn / depot_knn, rest -1);
+ *  infeasible_out[r][j] (uint8, row stride knn) = 1 where neighbour j of the last set has
+ *  demand > capacity + 1e-6; tile_out[r][kl+1+kd'+1][DGL_TILE_STRIDE] with columns
+ *  x, y, demand(/capacity for the last set), d, avg, sd, sin, cos, group flag. */
+DGL_API int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn,
+                  int32_t depot_knn, int32_t *idx_last_out, int32_t *idx_depot_out,
+                  uint8_t *infeasible_out, float *tile_out, dgl_stream_t stream);
+
+/* step_state.data [R][M][8] (CVRP/CVRPEnv.py:696,718,746,782,801). */
+DGL_API int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
+
+/* CVRPEnv.cal_length (CVRP/CVRPEnv.py:951-993). */
+DGL_API int dgl_cvrp_route_length(const dgl_cvrp_state_t *st, float *length_out, dgl_stream_t stream);
+
+/* --------------------------------------------------------------------- policy
+ * Encoder (1 block) + decoder (3 blocks) of TSPModel / CVRPModel
+ * (TSP/TSPModel.py:238-457, CVRP/CVRPModel.py:378-642), fp32 throughout. */
+#define DGL_PROBLEM_TSP 0
+#define DGL_PROBLEM_CVRP 1
+
+/* Size in floats of the packed weight buffer for dgl_policy_pack. */
+DGL_API int64_t dgl_policy_packed_floats(int32_t problem);
+
+/* Raw weights in the reference's state_dict layout (nn.Linear: weight [out][in]). */
+typedef struct {
+    const float *wq, *wk, *wv;  /* [128][128] */
+    const float *wc, *bc;       /* multi_head_combine [128][128], [128] */
+    const float *w1, *b1;       /* feedForward.W1 [512][128], [512] */
+    const float *w2, *b2;       /* feedForward.W2 [128][512], [128] */
+} dgl_block_weights_t;
+
+typedef struct {
+    int32_t problem;            /* DGL_PROBLEM_TSP (7 features) or _CVRP (9 features) */
+    const float *emb_w, *emb_b; /* encoder.embedding [128][F], [128] */
+    dgl_block_weights_t block[4]; /* encoder.layers.0, decoder.layers.0..2 */
+    const float *anchor_w[2], *anchor_b[2]; /* TSP: [0] = decoder.embedding_last_node;
+                                   CVRP: [0] = ..._not_via_depot, [1] = ..._via_depot */
+    const float *final_w, *final_b; /* decoder.Linear_final [1][128], [1] */
+} dgl_policy_weights_t;
+
+/* One-time re-layout of the weights into MFMA operand order (device -> device). */
+DGL_API int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl_stream_t stream);
+
+/* TSPModel.forward / CVRPModel.forward after the tile is built (TSP/TSPModel.py:257-339,
+ * CVRP/CVRPModel.py:397-523): logits, masked softmax, small-probability floor, greedy pick.
+ *  tile: row r starts at tile + r*tile_row_stride, n tokens of DGL_TILE_STRIDE floats each;
+ *  n <= DGL_MAX_TOKENS tokens per row.
+ *  TSP : tokens 0..n-2 candidates, token n-1 = current node (anchor 0).
+ *  CVRP: tokens 0..kl-1 direct candidates, kl = anchor 0 (current node),
+ *        kl+1..n-2 via-depot candidates, n-1 = anchor 1 (depot).
+ *  infeasible (CVRP, may be NULL): [R][knn_stride] 1 = direct move masked out.
+ *  Outputs (each may be NULL): logits_out [R][DGL_MAX_TOKENS] (token order as above),
+ *  prob_out [R][DGL_MAX_TOKENS] = floored softmax probability per token (anchors 0),
+ *  selected_out [R] = greedy action: TSP node id; CVRP action id (node, or node+N+1 via
+ *  depot); ties -> lowest action id. */
+typedef struct {
+    int32_t problem;
+    int32_t R;
+    int32_t n;            /* tokens per row at this step */
+    int32_t k_last;       /* CVRP: size of the direct set; TSP: n-1 */
+    int32_t N;            /* customers (CVRP) / nodes (TSP): via-depot offset is N+1 */
+    int32_t idx_stride;   /* row stride of idx_last / infeasible */
+    int32_t idx_dep_stride;
+    int32_t tile_row_stride; /* floats between consecutive rows of `tile` (>= n*DGL_TILE_STRIDE) */
+    const float *tile;
+    const int32_t *idx_last;    /* [R][idx_stride] */
+    const int32_t *idx_depot;   /* [R][idx_dep_stride] (CVRP) */
+    const uint8_t *infeasible;  /* [R][idx_stride] (CVRP) */
+    float *logits_out;
+    float *prob_out;
+    int32_t *selected_out;
+} dgl_policy_io_t;
+
+DGL_API int dgl_policy_forward(const float *packed_weights, const dgl_policy_io_t *io, dgl_stream_t stream);
+
+/* Dense [R][A] probabilities as the reference returns them (1e-20 where the action is not
+ * a candidate; TSP/TSPModel.py:328-337, CVRP/CVRPModel.py:495-516).  A = N (TSP) or
+ * 2(N+1) (CVRP). */
+DGL_API int dgl_policy_scatter_probs(const dgl_policy_io_t *io, const float *prob, float *dense_out,
+                             int32_t A, dgl_stream_t stream);
+
+/* ----------------------------------------------------------------------- beam
+ * Beamsearch.advance (utils/beamsearch.py:52-131) on dense log-probabilities:
+ * log_prob [G][beam][A]; scores [G][beam] in/out; step = current_step (>= 1; at step 1
+ * only beam 0 counts).  Outputs prev_k [G][beam], action [G][beam] (int32), best beam
+ * scores written back to `scores`.  Ties -> lowest flat index. */
+DGL_API int dgl_beam_advance(const float *log_prob, float *scores, int32_t G, int32_t beam, int32_t A,
+                     int32_t step, int32_t *prev_k_out, int32_t *action_out, dgl_stream_t stream);
+
+/* The same decision (utils/beamsearch.py:65-99) from the compact per-token probabilities
+ * (prob [R][DGL_MAX_TOKENS] as written
+ * by dgl_policy_forward, R = G*beam): candidates are the tokens' actions plus the implicit
+ * 1e-20 entries of every other action, exactly as the dense form. */
+DGL_API int dgl_beam_advance_compact(const dgl_policy_io_t *io, const float *prob, float *scores, int32_t G,
+                             int32_t beam, int32_t A, int32_t step, int32_t *prev_k_out,
+                             int32_t *action_out, dgl_stream_t stream);
+
+/* TSPEnv.perm_attr / CVRPEnv.perm_attr (TSP/TSPEnv.py:278-308, CVRP/CVRPEnv.py:536-581):
+ * re-index the per-row state by back-pointer, src -> dst (distinct buffers). */
+DGL_API int dgl_tsp_permute(const dgl_tsp_state_t *src, const dgl_tsp_state_t *dst, const int32_t *prev_k,
+                    int32_t beam, int32_t t, dgl_stream_t stream);
+DGL_API int dgl_cvrp_permute(const dgl_cvrp_state_t *src, const dgl_cvrp_state_t *dst, const int32_t *prev_k,
+                     int32_t beam, int32_t t, dgl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGL_AMD_H */

@@ -27,8 +27,6 @@ def load() -> ctypes.CDLL:
     ci = ctypes.c_int
     lib.dglref_dist_row.argtypes = [f32p, ci, ci, f32p]
     lib.dglref_dist_col.argtypes = [f32p, ci, ci, f32p]
-    lib.dglref_aten_sum.argtypes = [f32p, ctypes.c_int64]
-    lib.dglref_aten_sum.restype = ctypes.c_float
     lib.dglref_row_mean_std.argtypes = [f32p, ci, f32p, f32p]
     lib.dglref_tsp_knn.argtypes = [f32p, ci, ci, u8p, ci, i32p]
     lib.dglref_tsp_knn.restype = ci

@@ -17,9 +17,9 @@
  *         d_ij = sqrt(max(acc, 0))
  *     (asymmetric, non-zero diagonal).  Checked bit-for-bit against torch.cdist in
  *     tests/test_oracle_c.py.
- *   - row mean / population std of that matrix (TSP/TSPEnv.py:234-235): the mean in
- *     ATen's float summation order (8 lanes x 4 interleaved accumulators with a
- *     4-level cascade, then /N), the std via double accumulation.
+ *   - row mean / population std of that matrix (TSP/TSPEnv.py:234-235), accumulated in
+ *     double and rounded once (torch sums the mean in float with a cascade order that
+ *     depends on the CPU's SIMD width: equal to within a few ulp, not bit for bit).
  *   - masked k-nearest selection (TSP/TSPModel.py:79-91, CVRP/CVRPModel.py:88-125):
  *     key = d(last, j) + 100 for visited j, k smallest keys, lowest index wins a tie,
  *     result ascending by node index.
@@ -66,60 +66,15 @@ DGLREF_API void dglref_dist_col(const float *xy, int n, int c, float *out) {
     }
 }
 
-static int ceil_log2(int64_t x) {
-    if (x <= 2) return 1;
-    int b = 0;
-    uint64_t v = (uint64_t)(x - 1);
-    while (v) { ++b; v >>= 1; }
-    return b;
-}
-
-/* Sum of n floats in the order ATen's CPU sum kernel uses for a contiguous inner
- * reduction (8-lane vectors, 4 interleaved vector accumulators, 4-level cascade). */
-DGLREF_API float dglref_aten_sum(const float *row, int64_t n) {
-    enum { V = 8, ILP = 4, LEVELS = 4 };
-    int64_t vec_size = n / V, size = vec_size / ILP;
-    int lp = ceil_log2(size) / LEVELS;
-    if (lp < 4) lp = 4;
-    int64_t level_step = (int64_t)1 << lp, level_mask = level_step - 1;
-    float acc[LEVELS][ILP][V];
-    memset(acc, 0, sizeof acc);
-    int64_t i = 0;
-    while (i + level_step <= size) {
-        for (int64_t j = 0; j < level_step; ++j, ++i)
-            for (int k = 0; k < ILP; ++k)
-                for (int l = 0; l < V; ++l) acc[0][k][l] += row[(i * ILP + k) * V + l];
-        for (int j = 1; j < LEVELS; ++j) {
-            for (int k = 0; k < ILP; ++k)
-                for (int l = 0; l < V; ++l) { acc[j][k][l] += acc[j - 1][k][l]; acc[j - 1][k][l] = 0.0f; }
-            if ((i & (level_mask << (j * lp))) != 0) break;
-        }
-    }
-    for (; i < size; ++i)
-        for (int k = 0; k < ILP; ++k)
-            for (int l = 0; l < V; ++l) acc[0][k][l] += row[(i * ILP + k) * V + l];
-    for (int j = 1; j < LEVELS; ++j)
-        for (int k = 0; k < ILP; ++k)
-            for (int l = 0; l < V; ++l) acc[0][k][l] += acc[j][k][l];
-    for (int64_t v = size * ILP; v < vec_size; ++v)
-        for (int l = 0; l < V; ++l) acc[0][0][l] += row[v * V + l];
-    for (int k = 1; k < ILP; ++k)
-        for (int l = 0; l < V; ++l) acc[0][0][l] += acc[0][k][l];
-    float fin = 0.0f;
-    for (int64_t t = vec_size * V; t < n; ++t) fin += row[t];
-    for (int l = 0; l < V; ++l) fin += acc[0][0][l];
-    return fin;
-}
-
 /* avg[i] = mean_j d(i,j), sd[i] = population std_j d(i,j) for one instance */
 DGLREF_API void dglref_row_mean_std(const float *xy, int n, float *avg, float *sd) {
     float *row = (float *)malloc(sizeof(float) * (size_t)n);
     for (int i = 0; i < n; ++i) {
         dglref_dist_row(xy, n, i, row);
-        avg[i] = dglref_aten_sum(row, n) / (float)n;
         double s = 0.0, m;
         for (int j = 0; j < n; ++j) s += row[j];
         m = s / n;
+        avg[i] = (float)m;
         double q = 0.0;
         for (int j = 0; j < n; ++j) { double e = row[j] - m; q += e * e; }
         sd[i] = (float)sqrt(q / n);

@@ -70,7 +70,7 @@ def _save_weights(model, problem, wseed, ckpt, out_dir):
     reference's format ({'model_state_dict': ...})."""
     if ckpt:
         load_checkpoint_into(model, ckpt)
-        wname = "weights_" + os.path.splitext(os.path.basename(ckpt))[0]
+        return os.path.basename(ckpt)          # the .pt fixture itself holds the weights
     else:
         wname = f"weights_{problem.lower()}_init{wseed}"
     if wname not in _SAVED:
@@ -87,7 +87,7 @@ def load_checkpoint_into(model, path):
 
 
 def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None, out_dir=".",
-            wseed=789):
+            wseed=789, light=False):
     import torch
     TSPModel, TSPEnv, _, _, Beamsearch = _import_reference()
     torch.manual_seed(wseed)
@@ -182,6 +182,9 @@ def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ck
         out["tile"] = _pad([t.reshape(t.shape[0], -1) for t in rec["tile"]], (knn + 1) * 7, np.nan, np.float32)
     out.update(snaps)
     out["meta/weights"] = np.array(wname)
+    if light:                                   # big cases: keep tours, lengths and index sets only
+        for key in ("logits", "p", "capacity"):
+            out.pop(key, None)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: tour {tour.shape} mean length {length.mean():.5f} ties {int(out['tie'].sum())} "
@@ -189,7 +192,7 @@ def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ck
 
 
 def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None,
-             out_dir=".", wseed=789):
+             out_dir=".", wseed=789, light=False):
     import torch
     _, _, CVRPModel, CVRPEnv, Beamsearch = _import_reference()
     torch.manual_seed(wseed)
@@ -289,11 +292,24 @@ def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_
         out["tile"] = _pad([t.reshape(t.shape[0], -1) for t in rec["tile"]], ntok * 9, np.nan, np.float32)
     out.update(snaps)
     out["meta/weights"] = np.array(wname)
+    if light:                                   # big cases: keep tours, lengths and index sets only
+        for key in ("logits", "p", "capacity"):
+            out.pop(key, None)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: nodes {nodes.shape} mean length {length.mean():.5f} via-depot moves "
           f"{int(flags.sum())} -> {os.path.getsize(path) / 1e6:.2f} MB")
 
+
+TRAINED_CASES = {
+    # driven with the checkpoint fixtures trained by oracle/train_fixture_ckpt.py
+    "tsp_n100_b64_nn": ("tsp", dict(seed=789, B=64, N=100, knn=30)),
+    "tsp_n1000_b8_nn": ("tsp", dict(seed=789, B=8, N=1000, knn=30, light=True)),
+    "tsp_n200_b2_beam8_nn": ("tsp", dict(seed=123, B=2, N=200, knn=30, beam=8)),
+    "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
+    "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
+    "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),
+}
 
 CASES = {
     # name: (fn, kwargs)
@@ -318,16 +334,19 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--ckpt-tsp", default=None)
     ap.add_argument("--ckpt-cvrp", default=None)
-    ap.add_argument("--suffix", default="")
+    ap.add_argument("--trained", action="store_true", help="generate the checkpoint-driven cases")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for name, (kind, kw) in CASES.items():
+    cases = TRAINED_CASES if args.trained else CASES
+    ck_tsp = args.ckpt_tsp or (os.path.join(args.out, "ckpt_tsp_nn.pt") if args.trained else None)
+    ck_cvrp = args.ckpt_cvrp or (os.path.join(args.out, "ckpt_cvrp_nn.pt") if args.trained else None)
+    for name, (kind, kw) in cases.items():
         if args.only and args.only not in name:
             continue
         if kind == "tsp":
-            gen_tsp(name + args.suffix, out_dir=args.out, ckpt=args.ckpt_tsp, **kw)
+            gen_tsp(name, out_dir=args.out, ckpt=ck_tsp, **kw)
         else:
-            gen_cvrp(name + args.suffix, out_dir=args.out, ckpt=args.ckpt_cvrp, **kw)
+            gen_cvrp(name, out_dir=args.out, ckpt=ck_cvrp, **kw)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,98 @@
+"""Neighbourhood selection and state recurrences of the TSP step kernel vs the plain-C oracle
+on synthetic inputs, including the edge cases (ragged N, fewer unvisited nodes than k,
+duplicate points = exact key ties, clustered points, large k)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(device, xy, visit_order, knn, check_until=None):
+    """xy [B,N,2] float32 numpy; visit_order [B,N] permutation; drives the kernel with that order and
+    checks idx/avg/sd against the C oracle after every step."""
+    from dgl_amd.engine import TspEngine
+    from oracle import cref
+    lib = cref.load()
+    B, N = xy.shape[0], xy.shape[1]
+    eng = TspEngine(torch.from_numpy(xy).to(device), 1, knn)
+    eng.reset()
+    avg = eng.state["avg"].cpu().numpy().copy()
+    sd = eng.state["sd"].cpu().numpy().copy()
+    ref_avg, ref_sd = np.empty_like(avg), np.empty_like(sd)
+    for b in range(B):
+        lib.dglref_row_mean_std(np.ascontiguousarray(xy[b]), N, ref_avg[b], ref_sd[b])
+    np.testing.assert_allclose(avg, ref_avg, rtol=3e-7)
+    np.testing.assert_allclose(sd, ref_sd, rtol=3e-7)
+    order = torch.from_numpy(visit_order.astype(np.int32)).to(device)
+    visited = np.zeros((B, N), np.uint8)
+    steps = N - 1 if check_until is None else check_until
+    for t in range(1, steps + 1):
+        eng.step(order[:, t - 1].contiguous())
+        idx = eng.idx.cpu().numpy()
+        gavg, gsd = eng.state["avg"].cpu().numpy(), eng.state["sd"].cpu().numpy()
+        for b in range(B):
+            cur = int(visit_order[b, t - 1])
+            visited[b, cur] = 1
+            d = np.empty(N, np.float32)
+            # oracle recurrences start from the kernel's own previous state: bit-exact comparison
+            lib.dglref_step_features(np.ascontiguousarray(xy[b]), N, cur, N - t, 0, avg[b], sd[b], d)
+            ref_idx = np.full(knn, -1, np.int32)
+            k = lib.dglref_tsp_knn(np.ascontiguousarray(xy[b]), N, cur, visited[b], knn, ref_idx)
+            assert k == min(knn, N - t)
+            assert (idx[b] == ref_idx).all(), (t, b, idx[b], ref_idx)
+        assert np.array_equal(gavg, avg, equal_nan=True), t
+        assert np.array_equal(gsd, sd, equal_nan=True), t
+        avg, sd = gavg.copy(), gsd.copy()
+
+
+@pytest.mark.parametrize("N,knn", [(26, 30), (63, 30), (64, 5), (65, 30), (129, 30), (200, 64), (200, 100), (333, 1)])
+def test_uniform(device, N, knn):
+    rng = np.random.default_rng(N * 1000 + knn)
+    xy = rng.random((3, N, 2), dtype=np.float32)
+    order = np.stack([rng.permutation(N) for _ in range(3)])
+    _run_case(device, xy, order, knn)
+
+
+def test_duplicate_points_tie_break(device):
+    """Many coincident points: equal keys; the lowest index must win."""
+    rng = np.random.default_rng(7)
+    base = rng.random((2, 12, 2), dtype=np.float32)
+    xy = np.repeat(base, 10, axis=1)            # 120 nodes, 10 copies of each location
+    perm = rng.permutation(120)
+    xy = np.ascontiguousarray(xy[:, perm])
+    order = np.stack([rng.permutation(120) for _ in range(2)])
+    _run_case(device, xy, order, 30)
+
+
+def test_clustered(device):
+    rng = np.random.default_rng(11)
+    centers = rng.random((4, 2), dtype=np.float32)
+    xy = (centers[rng.integers(0, 4, size=(2, 500))] + 0.01 * rng.standard_normal((2, 500, 2))).astype(np.float32)
+    xy = np.clip(xy, 0, 1)
+    order = np.stack([rng.permutation(500) for _ in range(2)])
+    _run_case(device, xy, order, 30, check_until=120)
+
+
+def test_large_n(device):
+    rng = np.random.default_rng(5)
+    N = 5000
+    xy = rng.random((1, N, 2), dtype=np.float32)
+    order = rng.permutation(N)[None]
+    _run_case(device, xy, order, 30, check_until=40)
+
+
+def test_bad_arguments(device):
+    import ctypes
+    from dgl_amd import _lib
+    from dgl_amd.engine import TspEngine
+    eng = TspEngine(torch.rand(2, 40, 2, device=device), 1, 30)
+    lib = _lib.load()
+    st = eng.state["struct"]
+    sel = torch.zeros(2, dtype=torch.int32, device=device)
+    assert lib.dgl_tsp_step(ctypes.byref(st), 0, 1, 30, 0, 0, 0) == -1           # NULL selected
+    assert b"selected" in lib.dgl_last_error_string()
+    assert lib.dgl_tsp_step(ctypes.byref(st), sel.data_ptr(), 0, 30, 0, 0, 0) == -1   # t out of range
+    assert lib.dgl_tsp_step(ctypes.byref(st), sel.data_ptr(), 41, 30, 0, 0, 0) == -1
+    bad = _lib.TspState(2, 40, 1, 3, st.xy, st.avg, st.sd, st.visited, st.tour)
+    assert lib.dgl_tsp_reset(ctypes.byref(bad), 0) == -1

@@ -1,0 +1,120 @@
+"""GPU parity tests of the TSP path: HIP kernels (through the C ABI) vs the oracle and the
+golden vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, device, knn=None, rpi=1):
+    from dgl_amd.engine import TspEngine
+    xy = torch.from_numpy(case["xy"]).to(device)
+    return TspEngine(xy, rpi, int(case["meta/knn"]) if knn is None else knn)
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+def test_reset_matches_golden(name, device):
+    case, _ = load_golden(name)
+    eng = _engine(case, device)
+    eng.reset()
+    avg, sd = eng.state["avg"].cpu().numpy(), eng.state["sd"].cpu().numpy()
+    # reduction order differs from ATen's float cascade sum: a few ulp
+    np.testing.assert_allclose(avg, case["avg0"], rtol=3e-7, atol=0)
+    np.testing.assert_allclose(sd, case["std0"], rtol=3e-7, atol=0)
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+def test_teacher_forced_steps_match_golden(name, device):
+    """Drive the state with the reference's own tour; at every step compare the kNN index
+    sets (bit-exact), the normalised token tile and the logits (1e-3 relative)."""
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd._lib import PROBLEM_TSP, TILE_STRIDE
+    case, weights = load_golden(name)
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    tour = torch.from_numpy(case["tour"]).to(device=device, dtype=torch.int32)
+    N, knn = eng.N, eng.knn
+    eng.reset()
+    bad_rows = 0
+    max_logit_err = 0.0
+    max_tile_err = 0.0
+    tile_errs = []
+    agree = total = 0
+    for t in range(1, N):
+        eng.step(tour[:, t - 1].contiguous())
+        k = eng.k
+        idx = eng.idx.cpu().numpy()
+        gidx = case["idx"][t - 1]
+        row_ok = (idx[:, :k] == gidx[:, :k]).all(axis=1)
+        tie = case["tie"][t - 1]
+        bad_rows += int((~row_ok & ~tie).sum())
+        assert (idx[:, k:] == -1).all()
+        eng.forward(pol)
+        logits = eng.logits.cpu().numpy()[:, :k + 1]
+        g = case["logits"][t - 1][:, :k + 1]
+        ok = row_ok
+        if ok.any():
+            scale = np.abs(g[ok]).max(axis=1, keepdims=True)
+            max_logit_err = max(max_logit_err, float((np.abs(logits[ok] - g[ok]) / scale).max()))
+        if "tile" in case:
+            tile = eng.tile.cpu().numpy().reshape(eng.R, knn + 1, TILE_STRIDE)[:, :k + 1, :7]
+            gt = case["tile"][t - 1][:, :(k + 1) * 7].reshape(eng.R, k + 1, 7)
+            max_tile_err = max(max_tile_err, float(np.abs(tile[ok] - gt[ok]).max()))
+            tile_errs.append(np.abs(tile[ok] - gt[ok]).ravel())
+        sel = eng.selected.cpu().numpy()
+        agree += int((sel == case["tour"][:, t]).sum())
+        total += eng.R
+    print(f"{name}: kNN rows differing (non-tie) {bad_rows}, max rel logit err {max_logit_err:.2e}, "
+          f"max tile err {max_tile_err:.2e}, greedy pick agreement {agree}/{total}")
+    assert bad_rows == 0
+    assert max_logit_err < 1e-3
+    if "tile" in case:
+        # tile entries are (v - min) / range over the neighbourhood: where the range of a running
+        # feature is tiny, a 1-ulp difference in avg/sd (different summation order at reset, amplified
+        # by N/u in the recurrences) is magnified; bound the bulk tightly and the tail loosely
+        errs = np.concatenate(tile_errs)
+        assert np.quantile(errs, 0.999) < 2e-5, np.quantile(errs, 0.999)
+        assert max_tile_err < 5e-3
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8"])
+def test_state_data_matches_golden(name, device):
+    case, _ = load_golden(name)
+    eng = _engine(case, device)
+    tour = torch.from_numpy(case["tour"]).to(device=device, dtype=torch.int32)
+    eng.reset()
+    snaps = sorted(int(k[4:].split("/")[0]) for k in case if k.startswith("snap") and k.endswith("/data"))
+    for t in range(1, eng.N):
+        eng.step(tour[:, t - 1].contiguous())
+        if t in snaps:
+            data = eng.data().cpu().numpy()
+            g = case[f"snap{t}/data"]
+            u = eng.N - t
+            # running features amplify a 1-ulp start difference by ~N/u
+            tol = 4e-7 * eng.N / u
+            np.testing.assert_allclose(data[:, :, :3], g[:, :, :3], rtol=2e-7, atol=1e-7)
+            np.testing.assert_allclose(data[:, :, 3:5], g[:, :, 3:5], rtol=tol, atol=tol)
+            np.testing.assert_allclose(data[:, :, 5:], g[:, :, 5:], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+def test_greedy_rollout_length(name, device):
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd._lib import PROBLEM_TSP
+    case, weights = load_golden(name)
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    start = torch.from_numpy(case["start"]).to(device=device, dtype=torch.int32).repeat(eng.B)
+    length = eng.greedy_rollout(pol, start).cpu().numpy()
+    tour = eng.state["tour"].cpu().numpy()
+    for r in range(eng.R):
+        assert sorted(tour[r].tolist()) == list(range(eng.N)), "not a permutation"
+    same = (tour == case["tour"]).all(axis=1)
+    print(f"{name}: identical tours {int(same.sum())}/{eng.R}; mean length {length.mean():.5f} vs "
+          f"{case['length'].mean():.5f}")
+    # lengths of identical tours must agree to float rounding
+    if same.any():
+        np.testing.assert_allclose(length[same], case["length"][same], rtol=2e-6)

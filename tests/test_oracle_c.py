@@ -1,0 +1,115 @@
+"""Pins the plain-C restatement (oracle/dgl_ref.c) against torch and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cref
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return cref.load()
+
+
+@pytest.mark.parametrize("N", [26, 50, 101, 1000])
+def test_chain_distance_is_cdist_matmul_path(lib, N):
+    """The C chain reproduces, bit for bit, the 4-term matrix product torch.cdist evaluates for
+    more than 25 points; the final sqrt is IEEE here, whereas this torch build's CPU sqrt goes
+    through a vector-math library that is off by one ulp for ~0.6 % of inputs."""
+    torch.manual_seed(N)
+    x = torch.rand(2, N, 2)
+    n = x.pow(2).sum(-1, True)
+    a = torch.cat([x.mul(-2), n, torch.ones_like(n)], -1)
+    b = torch.cat([x, torch.ones_like(n), n], -1)
+    acc = a.matmul(b.mT).clamp_min(0).numpy()
+    want = np.sqrt(acc)                                   # IEEE sqrt of torch's own accumulator
+    cd = torch.cdist(x, x).numpy()
+    row, col = np.empty(N, np.float32), np.empty(N, np.float32)
+    for bi in range(2):
+        xy = np.ascontiguousarray(x[bi].numpy())
+        for i in range(0, N, max(1, N // 17)):
+            lib.dglref_dist_row(xy, N, i, row)
+            lib.dglref_dist_col(xy, N, i, col)
+            assert np.array_equal(row, want[bi, i])
+            assert np.array_equal(col, want[bi, :, i])
+    assert np.abs(cd - want).max() <= np.spacing(np.float32(cd.max()))
+    assert (cd != want).mean() < 0.02
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn"])
+def test_tsp_knn_sets_match_reference(lib, name):
+    case, _ = load_golden(name)
+    xy, tour, knn = case["xy"], case["tour"], int(case["meta/knn"])
+    B, N = xy.shape[0], xy.shape[1]
+    steps = range(1, N) if N <= 100 else list(range(1, 40)) + list(range(N - 40, N))
+    bad = 0
+    for b in range(min(B, 8)):
+        pts = np.ascontiguousarray(xy[b])
+        for t in steps:
+            visited = np.zeros(N, np.uint8)
+            visited[tour[b, :t]] = 1
+            idx = np.full(knn, -1, np.int32)
+            k = lib.dglref_tsp_knn(pts, N, int(tour[b, t - 1]), visited, knn, idx)
+            g = case["idx"][t - 1][b]
+            assert k == min(knn, N - t)
+            if not np.array_equal(idx[:k], g[:k]) and not case["tie"][t - 1][b]:
+                bad += 1
+    assert bad == 0
+
+
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20"])
+def test_cvrp_knn_sets_match_reference(lib, name):
+    import ctypes
+    case, _ = load_golden(name)
+    B, N = case["node_xy"].shape[0], case["node_xy"].shape[1]
+    knn, kd = int(case["meta/knn"]), int(case["meta/depot_knn"])
+    nodes = case["nodes"]
+    for b in range(B):
+        pts = np.ascontiguousarray(np.concatenate([case["depot_xy"][b][None], case["node_xy"][b]], 0))
+        for t in range(1, N):
+            visited = np.zeros(N + 1, np.uint8)
+            visited[nodes[b, :t]] = 1
+            il, idp = np.full(knn, -1, np.int32), np.full(kd, -1, np.int32)
+            kl = ctypes.c_int(0)
+            kdd = lib.dglref_cvrp_knn(pts, N, int(nodes[b, t - 1]), visited, knn, kd, il, idp, ctypes.byref(kl))
+            assert kdd == min(kd, N - t) and kl.value == min(knn, kdd)
+            assert np.array_equal(il[:kl.value], case["idx_last"][t - 1][b][:kl.value]), (b, t)
+            assert np.array_equal(idp[:kdd], case["idx_dep"][t - 1][b][:kdd]), (b, t)
+
+
+def test_tsp_state_recurrences_match_reference(lib):
+    case, _ = load_golden("tsp_n100_b8")
+    xy, tour = case["xy"], case["tour"]
+    B, N = xy.shape[0], xy.shape[1]
+    for b in range(B):
+        pts = np.ascontiguousarray(xy[b])
+        avg, sd = np.empty(N, np.float32), np.empty(N, np.float32)
+        lib.dglref_row_mean_std(pts, N, avg, sd)
+        np.testing.assert_allclose(avg, case["avg0"][b], rtol=3e-7)
+        np.testing.assert_allclose(sd, case["std0"][b], rtol=3e-7)
+        d = np.empty(N, np.float32)
+        for t in range(1, N):
+            lib.dglref_step_features(pts, N, int(tour[b, t - 1]), N - t, 0, avg, sd, d)
+            if f"snap{t}/data" in case:
+                g = case[f"snap{t}/data"][b]
+                tol = 4e-7 * N / (N - t)
+                np.testing.assert_allclose(d, g[:, 2], rtol=2e-7, atol=1e-7)
+                np.testing.assert_allclose(avg, g[:, 3], rtol=tol, atol=tol)
+                np.testing.assert_allclose(sd, g[:, 4], rtol=tol, atol=tol)
+                s, c = np.empty(N, np.float32), np.empty(N, np.float32)
+                lib.dglref_direction(pts, N, int(tour[b, 0]), s, c)
+                np.testing.assert_allclose(s, g[:, 5], rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(c, g[:, 6], rtol=1e-5, atol=1e-6)
+
+
+def test_lengths_match_reference(lib):
+    case, _ = load_golden("tsp_n100_b8")
+    for b in range(case["xy"].shape[0]):
+        got = lib.dglref_tsp_length(np.ascontiguousarray(case["xy"][b]), np.ascontiguousarray(case["tour"][b]), 100)
+        assert abs(got - case["length"][b]) < 1e-5 * case["length"][b]
+    case, _ = load_golden("cvrp_n100_b8")
+    for b in range(case["node_xy"].shape[0]):
+        pts = np.ascontiguousarray(np.concatenate([case["depot_xy"][b][None], case["node_xy"][b]], 0))
+        got = lib.dglref_cvrp_length(pts, np.ascontiguousarray(case["nodes"][b]), np.ascontiguousarray(case["flags"][b]), 100)
+        assert abs(got - case["length"][b]) < 1e-5 * case["length"][b]

@@ -1,0 +1,100 @@
+"""Pins the CPU oracle (oracle/dgl_oracle.py) to the vectors captured from the imported
+reference (tests/golden/*.npz, written by oracle/make_goldens.py).
+
+On the machine/torch build that generated the vectors the restatement is bit-equal to the
+reference (same ATen/BLAS kernels on the same shapes); elsewhere float results may differ
+in the last bits (different SIMD width / BLAS kernels), so indices are compared exactly
+only where the recorded decision margin allows and floats with a tight tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle.dgl_oracle import CVRPOracle, TSPOracle, cvrp_rollout, tsp_rollout
+
+TSP_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "tsp_*.npz")))
+CVRP_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "cvrp_*.npz")))
+
+
+def _same_platform(case):
+    return (str(case["meta/torch"]) == torch.__version__
+            and str(case["meta/cpu"]) == torch.backends.cpu.get_cpu_capability())
+
+
+def _cmp(a, b, exact, what, rtol=2e-5, atol=2e-6):
+    if exact:
+        assert np.array_equal(a, b, equal_nan=True), what
+    else:
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.mark.parametrize("name", TSP_CASES)
+def test_tsp_oracle_reproduces_reference(name):
+    case, weights = load_golden(name)
+    if case["xy"].shape[1] >= 1000 and case["xy"].shape[0] > 4:
+        pytest.skip("large case: covered by the GPU tests (keeps the CPU suite short)")
+    exact = _same_platform(case)
+    oracle = TSPOracle(weights, int(case["meta/knn"]))
+    rec = []
+    out = tsp_rollout(oracle, torch.from_numpy(case["xy"]), torch.from_numpy(case["start"]).long(),
+                      beam=int(case["meta/beam"]), pomo=int(case["meta/pomo"]),
+                      record=lambda s, o, r: rec.append({k: v.numpy().copy() for k, v in r.items() if k != "probs"}))
+    if exact:
+        assert np.array_equal(out["tour"].numpy(), case["tour"])
+    _cmp(out["length"].numpy(), case["length"], exact, "tour length", rtol=1e-5)
+    for s, r in enumerate(rec):
+        k = r["idx"].shape[1]
+        if exact:
+            assert np.array_equal(r["idx"], case["idx"][s][:, :k]), f"kNN set, step {s + 1}"
+        if "logits" in case and exact:
+            _cmp(r["logits"], case["logits"][s][:, :k + 1], exact, f"logits, step {s + 1}")
+            _cmp(r["p"], case["p"][s][:, :k], exact, f"probabilities, step {s + 1}")
+        if "tile" in case and exact:
+            _cmp(r["tile"].reshape(r["tile"].shape[0], -1), case["tile"][s][:, :(k + 1) * 7], exact, "tile")
+
+
+@pytest.mark.parametrize("name", CVRP_CASES)
+def test_cvrp_oracle_reproduces_reference(name):
+    case, weights = load_golden(name)
+    if case["node_xy"].shape[1] >= 1000 and case["node_xy"].shape[0] > 2:
+        pytest.skip("large case: covered by the GPU tests (keeps the CPU suite short)")
+    exact = _same_platform(case)
+    oracle = CVRPOracle(weights, int(case["meta/knn"]), int(case["meta/depot_knn"]))
+    rec = []
+    out = cvrp_rollout(oracle, torch.from_numpy(case["depot_xy"]), torch.from_numpy(case["node_xy"]),
+                       torch.from_numpy(case["demand"]), torch.from_numpy(case["start"]).long(),
+                       beam=int(case["meta/beam"]), pomo=int(case["meta/pomo"]),
+                       record=lambda s, o, r: rec.append(
+                           {k: v.numpy().copy() for k, v in r.items() if k != "probs"} | {"cap": o.capacity.numpy().copy()}))
+    if exact:
+        assert np.array_equal(out["nodes"].numpy(), case["nodes"])
+        assert np.array_equal(out["flags"].numpy(), case["flags"])
+    _cmp(out["length"].numpy(), case["length"], exact, "route length", rtol=1e-5)
+    for s, r in enumerate(rec):
+        kl, kd = r["idx_last"].shape[1], r["idx_dep"].shape[1]
+        if exact:
+            assert np.array_equal(r["idx_last"], case["idx_last"][s][:, :kl])
+            assert np.array_equal(r["idx_dep"], case["idx_dep"][s][:, :kd])
+            if "logits" in case:
+                _cmp(r["logits"], case["logits"][s][:, :kl + kd + 2], exact, f"logits, step {s + 1}")
+                _cmp(r["cap"], case["capacity"][s], exact, "capacity")
+
+
+def test_golden_feasibility_cvrp():
+    """Sanity of the captured CVRP routes themselves: every customer once, loads <= capacity."""
+    for name in CVRP_CASES:
+        case, _ = load_golden(name)
+        nodes, flags, dem = case["nodes"], case["flags"], case["demand"]
+        rpi = nodes.shape[0] // dem.shape[0]
+        for r in range(nodes.shape[0]):
+            assert sorted(nodes[r].tolist()) == list(range(1, nodes.shape[1] + 1))
+            load = 0.0
+            for p in range(nodes.shape[1]):
+                if flags[r, p]:
+                    load = 0.0
+                load += float(dem[r // rpi, nodes[r, p] - 1])
+                assert load <= 1.0 + 1e-5
