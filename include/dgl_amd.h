@@ -196,6 +196,8 @@ typedef struct {
     int32_t *selected_out;
 } dgl_policy_io_t;
 
+/* Runs the network described above for every row (TSP/TSPModel.py:174-231,
+ * CVRP/CVRPModel.py:278-371, test/valid branch). */
 DGL_API int dgl_policy_forward(const float *packed_weights, const dgl_policy_io_t *io, dgl_stream_t stream);
 
 /* Dense [R][A] probabilities as the reference returns them (1e-20 where the action is not
