@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the DGL greedy decode path on MI355X.
+
+A *step* is one full greedy decode of one batch of synthetic instances (reset, N-1 policy
+decisions with the fused state-update/kNN/tile kernel in between, tour length): one pass
+of the hot path over one batch.  Default workload: TSP-1000, 512 uniform instances per GPU,
+k = 30 (BASELINE.json configs[1]); ``--problem cvrp`` runs CVRP-1000 (configs[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  ``value`` is whole-job instances/s (all ranks; instances are
+independent, so ranks shard them with no data-path collective: weak scaling); only the
+tour-length statistics are all-reduced (RCCL) at the end.  ``roofline`` describes the
+dominant kernel (the fp32-MFMA policy network), timed with HIP events on the launch stream
+inside the timed region; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
+the workload's batch and at a batch large enough to fill the chip.  ``cpu_baseline`` is the
+oracle (the PyTorch-CPU restatement of the reference path) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X dense fp32 MFMA (v_mfma_f32_32x32x2_f32), spec
+PEAK_HBM_GBS = 8000.0             # MI355X HBM3E, spec
+
+
+def policy_flops_per_row(n: int, feat: int, anchors: int) -> float:
+    """Forward flops of the 1+3-block transformer for one row of n tokens (2 flops per MAC):
+    per block n*393216 (q,k,v,combine,FF) + 512 n^2 (QK^T and PV over 8 heads x 16)."""
+    return 4 * (n * 393216 + 512 * n * n) + n * 2 * feat * 128 + 32768 * anchors + n * 256
+
+
+def knn_bytes_per_row(nodes: int, k: int, cvrp: bool) -> float:
+    """Algorithmic HBM bytes of the fused state-update + kNN + tile kernel per row and step."""
+    if cvrp:
+        m = nodes + 1
+        return 28 * m + m / 4 + 8 * k
+    return 24 * nodes + nodes / 8 + 8 * k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--problem", choices=["tsp", "cvrp"], default="tsp")
+    ap.add_argument("--nodes", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=512, help="instances per GPU")
+    ap.add_argument("--knn", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="instances decoded by the CPU baseline")
+    ap.add_argument("--no-aux", action="store_true", help="skip the saturating-batch kNN measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dgl_amd import build
+    build.build()                                   # no-op when the in-tree library is current
+    from dgl_amd._lib import PROBLEM_CVRP, PROBLEM_TSP
+    from dgl_amd.engine import CvrpEngine, PackedPolicy, TspEngine
+    from dgl_amd.weights import random_state_dict
+
+    cvrp = args.problem == "cvrp"
+    N, B = args.nodes, args.batch
+    knn = args.knn or (15 if cvrp else 30)
+    gen = torch.Generator().manual_seed(789 + rank)
+    if cvrp:
+        depot = torch.rand(B, 1, 2, generator=gen)
+        nodes = torch.rand(B, N, 2, generator=gen)
+        demand = torch.randint(1, 200, (B, N), generator=gen) / 500.0      # CVRP/CVRPEnv.py:42-48
+        xy = torch.cat((depot, nodes), 1).to(dev)
+        dem = torch.cat((torch.zeros(B, 1), demand), 1).to(dev)
+        eng = CvrpEngine(xy, dem, 1, knn, knn)
+        policy = PackedPolicy(random_state_dict("CVRP", 789), PROBLEM_CVRP, dev)
+        start_node = int(torch.randperm(N, generator=gen)[0])
+        start = torch.full((B,), start_node + 2 + N, dtype=torch.int32, device=dev)   # CVRP/CVRPTester.py:183
+        n_tok, feat, anchors = 2 * knn + 2, 9, 2
+    else:
+        xy = torch.rand(B, N, 2, generator=gen).to(dev)
+        eng = TspEngine(xy, 1, knn)
+        policy = PackedPolicy(random_state_dict("TSP", 789), PROBLEM_TSP, dev)
+        start = torch.full((B,), int(torch.randperm(N, generator=gen)[0]), dtype=torch.int32, device=dev)
+        n_tok, feat, anchors = knn + 1, 7, 1
+    decisions = N - 1
+
+    ev_policy, ev_knn = [], []
+
+    def rollout(sample: bool):
+        eng.reset()
+        eng.step(start)
+        s = 0
+        while eng.t < N:
+            probe = sample and (s % 16 == 8) and eng.k == knn
+            if probe:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            eng.forward(policy, want_logits=False, want_prob=False)
+            if probe:
+                e1.record()
+            eng.step(eng.selected)
+            if probe:
+                e2.record()
+                ev_policy.append((e0, e1))
+                ev_knn.append((e1, e2))
+            s += 1
+        return eng.tour_length()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rollout(False)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        length = rollout(True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([float(length.double().sum()), float(B), elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(stats[:2], op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+    mean_len = float(stats[0] / stats[1])
+
+    if rank == 0:
+        ms_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
+        ms_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
+        flops = policy_flops_per_row(n_tok, feat, anchors) * B
+        ach_tf = flops / (ms_policy * 1e-3) / 1e12 if ms_policy > 0 else 0.0
+        bytes_knn = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * B
+        ach_gbs = bytes_knn / (ms_knn * 1e-3) / 1e9 if ms_knn > 0 else 0.0
+        out = {
+            "metric": f"instances/sec, {args.problem.upper()}-{N} greedy decode (node selection)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "instances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.problem.upper()}-{N} greedy decode, {B} uniform instances per GPU, "
+                                   f"k={knn}" + (f"/{knn}" if cvrp else "") + ", random-init weights",
+                       "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}"},
+            "decode_steps_per_s": args.steps * decisions / elapsed,
+            "row_decisions_per_s": world * B * args.steps * decisions / elapsed,
+            "mean_tour_length": mean_len,
+            "roofline": {"kernel": "policy_kernel", "bound": "mfma", "achieved": ach_tf,
+                         "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_MATRIX_TFLOPS,
+                         "traffic": None, "avg_launch_ms": ms_policy, "flops_per_launch": flops,
+                         "samples": len(ev_policy)},
+            "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+                             "avg_launch_ms": ms_knn, "bytes_per_launch": bytes_knn, "rows": B},
+        }
+        if not args.no_aux and world == 1:
+            out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, args.problem, N, knn)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.problem, N, knn, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def knn_saturating(dev, problem: str, N: int, knn: int, rows: int = 16384):
+    """The HBM-bound kernel at a batch that fills the chip (same kernel, same N)."""
+    from dgl_amd.engine import CvrpEngine, TspEngine
+    g = torch.Generator().manual_seed(1)
+    cvrp = problem == "cvrp"
+    if cvrp:
+        xy = torch.rand(rows, N + 1, 2, generator=g).to(dev)
+        dem = torch.cat((torch.zeros(rows, 1), torch.randint(1, 200, (rows, N), generator=g) / 500.0), 1).to(dev)
+        eng = CvrpEngine(xy, dem, 1, knn, knn)
+        sel = torch.full((rows,), 7 + 2 + N, dtype=torch.int32, device=dev)
+    else:
+        xy = torch.rand(rows, N, 2, generator=g).to(dev)
+        eng = TspEngine(xy, 1, knn)
+        sel = torch.full((rows,), 7, dtype=torch.int32, device=dev)
+    eng.reset()
+    eng.step(sel)
+    nxt = [torch.full((rows,), 100 + i + (0 if not cvrp else 0), dtype=torch.int32, device=dev) for i in range(12)]
+    torch.cuda.synchronize()
+    evs = []
+    for i in range(12):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.step(nxt[i])
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs[2:])
+    ms = sum(ms) / len(ms)
+    by = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * rows
+    gbs = by / (ms * 1e-3) / 1e9
+    return {"rows": rows, "avg_launch_ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": by}
+
+
+def cpu_baseline(problem: str, N: int, knn: int, sample: int):
+    """The oracle (PyTorch-CPU restatement of the reference path: dense distance matrix, full
+    argsort, [R,N] probability scatter, top-k) decoding `sample` instances of the same workload."""
+    from dgl_amd.weights import random_state_dict
+    from oracle.dgl_oracle import CVRPOracle, TSPOracle, cvrp_rollout, tsp_rollout
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(789)
+    with torch.no_grad():
+        if problem == "cvrp":
+            depot, nodes = torch.rand(sample, 2, generator=g), torch.rand(sample, N, 2, generator=g)
+            demand = torch.randint(1, 200, (sample, N), generator=g) / 500.0
+            orc = CVRPOracle(random_state_dict("CVRP", 789), knn, knn)
+            t0 = time.perf_counter()
+            cvrp_rollout(orc, depot, nodes, demand, torch.tensor([3]))
+        else:
+            xy = torch.rand(sample, N, 2, generator=g)
+            orc = TSPOracle(random_state_dict("TSP", 789), knn)
+            t0 = time.perf_counter()
+            tsp_rollout(orc, xy, torch.tensor([3]))
+        dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "instances/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} instances of {problem.upper()}-{N}, one full greedy decode, "
+                      f"torch {torch.__version__} CPU, {threads} threads, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64.so.7).  It must be the one already
+    # resident when this library is loaded, so that both resolve to a single runtime
+    # instance and share devices, streams and allocations.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DglError(f"{LIB_PATH} is missing: build it with `python -m dgl_amd.build` "
                        "(there is no fallback path)")

@@ -156,3 +156,8 @@ class TspEngine:
             self.forward(policy, want_logits=False, want_prob=False)
             self.step(self.selected)
         return self.tour_length()
+
+
+class CvrpEngine:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("CVRP engine: work in progress")

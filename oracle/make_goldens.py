@@ -185,9 +185,12 @@ def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ck
     if light:                                   # big cases: keep tours, lengths and index sets only
         for key in ("logits", "p", "capacity"):
             out.pop(key, None)
+    if light == "tours":                        # population cases: tours and lengths only
+        for key in ("idx", "tie", "idx_last", "idx_dep"):
+            out.pop(key, None)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: tour {tour.shape} mean length {length.mean():.5f} ties {int(out['tie'].sum())} "
+    print(f"{name}: tour {tour.shape} mean length {length.mean():.5f} ties {int(np.stack(rec['tie']).sum())} "
           f"-> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
@@ -295,6 +298,9 @@ def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_
     if light:                                   # big cases: keep tours, lengths and index sets only
         for key in ("logits", "p", "capacity"):
             out.pop(key, None)
+    if light == "tours":                        # population cases: tours and lengths only
+        for key in ("idx", "tie", "idx_last", "idx_dep"):
+            out.pop(key, None)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: nodes {nodes.shape} mean length {length.mean():.5f} via-depot moves "
@@ -306,6 +312,8 @@ TRAINED_CASES = {
     "tsp_n100_b64_nn": ("tsp", dict(seed=789, B=64, N=100, knn=30)),
     "tsp_n1000_b8_nn": ("tsp", dict(seed=789, B=8, N=1000, knn=30, light=True)),
     "tsp_n200_b2_beam8_nn": ("tsp", dict(seed=123, B=2, N=200, knn=30, beam=8)),
+    "tsp_n100_b512_nn_tours": ("tsp", dict(seed=4242, B=512, N=100, knn=30, light="tours")),
+    "cvrp_n100_b256_nn_tours": ("cvrp", dict(seed=4242, B=256, N=100, knn=15, depot_knn=15, light="tours")),
     "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
     "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
     "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),
