@@ -1,6 +1,313 @@
+// CVRP environment state on the device: reset, fused step (action decoding, capacity,
+// running features) + the two neighbourhoods (current node, depot) + token tile, dense state
+// materialisation, route length, beam permutation.
+//
+// One wave64 owns one row.  Nodes 0..N (0 = depot), M = N + 1 points per instance.  The
+// feasibility mask of the reference (ninf_mask [R][M], CVRP/CVRPEnv.py:633-637) is not stored:
+// it is capacity + 1e-6 < demand[j], evaluated where needed.
 #include "common.h"
-extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *, dgl_stream_t) { return dgl_set_error(DGL_ERR_UNSUPPORTED, "todo"); }
-extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *, const int32_t *, int32_t, int32_t, int32_t, int32_t *, int32_t *, uint8_t *, float *, dgl_stream_t) { return dgl_set_error(DGL_ERR_UNSUPPORTED, "todo"); }
-extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *, int32_t, float *, dgl_stream_t) { return dgl_set_error(DGL_ERR_UNSUPPORTED, "todo"); }
-extern "C" int dgl_cvrp_route_length(const dgl_cvrp_state_t *, float *, dgl_stream_t) { return dgl_set_error(DGL_ERR_UNSUPPORTED, "todo"); }
-extern "C" int dgl_cvrp_permute(const dgl_cvrp_state_t *, const dgl_cvrp_state_t *, const int32_t *, int32_t, int32_t, dgl_stream_t) { return dgl_set_error(DGL_ERR_UNSUPPORTED, "todo"); }
+#include "select.h"
+#include "state_common.h"
+
+#define CVRP_F 8       // x, y, demand, d, avg, sd, sin, cos (+ group flag in column 8 of the tile)
+
+__global__ __launch_bounds__(256) void cvrp_reset_kernel(dgl_cvrp_state_t st) {
+    dgl_reset_rows(st.xy, st.N + 1, st.rows_per_instance, st.avg, st.sd, st.visited);
+    if (blockIdx.x == 0)
+        for (int p = threadIdx.x; p < st.rows_per_instance; p += blockDim.x)
+            st.capacity[(size_t)blockIdx.y * st.rows_per_instance + p] = 1.0f;
+}
+
+struct CvrpRowCtx {
+    const float *xyb, *demb;
+    float xc, yc, nc, x0, y0, n0;
+    size_t rowM;
+};
+
+// raw data row of node j (CVRP/CVRPEnv.py:696,718,746,782,801)
+__device__ __forceinline__ void cvrp_features(const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
+    const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
+    const float d0 = dgl_chain_dist(x, y, nj, cx.x0, cx.y0, cx.n0);        // d(j, depot)
+    const float den = __fadd_rn(d0, 1e-7f);
+    f[0] = x;
+    f[1] = y;
+    f[2] = cx.demb[j];
+    f[3] = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);                   // d(j, current)
+    f[4] = st.avg[cx.rowM + j];
+    f[5] = st.sd[cx.rowM + j];
+    f[6] = __fdiv_rn(__fsub_rn(cx.y0, y), den);
+    f[7] = __fdiv_rn(__fsub_rn(cx.x0, x), den);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
+                                                              int t, int knn, int depot_knn,
+                                                              int32_t *__restrict__ idx_last_out,
+                                                              int32_t *__restrict__ idx_dep_out,
+                                                              uint8_t *__restrict__ infeasible_out,
+                                                              float *__restrict__ tile_out, int lds_per_wave) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * WAVES + wave;
+    if (r >= st.R) return;
+    const int N = st.N, M = N + 1, W = (M + 63) / 64;
+    float *keysL = lds + (size_t)wave * lds_per_wave;
+    float *keysD = keysL + M;
+    float *tile = keysD + M;
+    float *scratch = tile + (knn + depot_knn + 2) * DGL_TILE_STRIDE;
+
+    const int b = r / st.rows_per_instance;
+    CvrpRowCtx cx;
+    cx.xyb = st.xy + (size_t)b * M * 2;
+    cx.demb = st.demand + (size_t)b * M;
+    cx.rowM = (size_t)r * M;
+
+    // ---- action decoding, capacity (CVRP/CVRPEnv.py:612-631)
+    const int act = action[r];
+    const bool via = act > N;
+    const int cur = via ? act - (N + 1) : act;
+    const float dem_cur = cx.demb[cur];
+    const float cap_old = st.capacity[r];
+    float cap = via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur);
+    const float cap_eps = __fadd_rn(cap, 0.000001f);          // feasibility uses the un-nudged capacity
+
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
+
+    const int u = M - t;                                       // CVRP/CVRPEnv.py:662
+    const float up1 = (float)(u + 1), uf = (float)u;
+    const bool want_knn = (idx_last_out != nullptr) && (t < N);
+    float minL = INFINITY, minD = INFINITY;
+    uint64_t *vis = st.visited + (size_t)r * W;
+    for (int j0 = 0; j0 < M; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long word = vis[j0 >> 6];
+        if (j < M) {
+            const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
+            const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);
+            const float a0 = st.avg[cx.rowM + j], s0 = st.sd[cx.rowM + j];
+            const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);            // :711
+            const float e = __fsub_rn(dcol, a0);
+            float item = __fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf);   // :733
+            if (item < 0.0f) item = 0.0f;                                                     // :735-736
+            st.avg[cx.rowM + j] = a1;
+            st.sd[cx.rowM + j] = sqrtf(item);
+            if (want_knn) {
+                const bool out = ((word >> (j & 63)) & 1ull) || (j == cur) || (j == 0);
+                const float kl = out ? INFINITY : dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
+                const float kd = out ? INFINITY : dgl_chain_dist(cx.x0, cx.y0, cx.n0, x, y, nj);   // dis[0][j]
+                keysL[j] = kl;
+                keysD[j] = kd;
+                minL = fminf(minL, kl);
+                minD = fminf(minD, kd);
+            }
+        }
+    }
+    if (want_knn) {
+        // CVRPModel.get_knn_state nudges near-zero capacities in place before it divides by them
+        // (CVRP/CVRPModel.py:164-166); the nudged value is what the next step starts from.
+        if (cap < 0.00001f) cap = __fadd_rn(cap, 0.0000001f);
+    }
+    if (lane == 0) {
+        st.capacity[r] = cap;
+        st.nodes[(size_t)r * N + (t - 1)] = cur;
+        st.flags[(size_t)r * N + (t - 1)] = via ? 1 : 0;
+        vis[cur >> 6] |= 1ull << (cur & 63);
+    }
+    if (!want_knn) return;
+
+    wave_lds_sync();
+    const int kd = min(depot_knn, N - t);                      // CVRP/CVRPModel.py:58,88
+    const int kl = min(knn, kd);                               // :123
+    const bool low = cap < 0.00001f;
+    int32_t *il = idx_last_out + (size_t)r * knn;
+    int32_t *id = idx_dep_out + (size_t)r * depot_knn;
+    uint8_t *inf_row = infeasible_out + (size_t)r * knn;
+    float *tileL = tile, *tileD = tile + (kl + 1) * DGL_TILE_STRIDE;
+
+    const float TL = wave_kth_smallest(keysL, M, kl, minL, scratch);
+    wave_emit_selected(keysL, M, kl, TL, [&](int j, int rank) {
+        il[rank] = j;
+        float *f = tileL + rank * DGL_TILE_STRIDE;
+        cvrp_features(st, cx, j, f);
+        inf_row[rank] = cap_eps < f[2] ? 1 : 0;                                   // CVRP/CVRPEnv.py:634
+        f[2] = low ? 1.1f : __fdiv_rn(f[2], cap);                                 // CVRP/CVRPModel.py:172-174
+    });
+    wave_lds_sync();                                           // scratch is reused by the second search
+    const float TD = wave_kth_smallest(keysD, M, kd, minD, scratch);
+    wave_emit_selected(keysD, M, kd, TD, [&](int j, int rank) {
+        id[rank] = j;
+        float *f = tileD + rank * DGL_TILE_STRIDE;
+        cvrp_features(st, cx, j, f);
+        const float x = f[0], y = f[1];
+        f[3] = dgl_chain_dist(x, y, dgl_sqnorm(x, y), cx.x0, cx.y0, cx.n0);      // distance_to_depot, :180-183
+    });
+    for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
+    for (int e = kd + lane; e < depot_knn; e += 64) id[e] = -1;
+    // anchors: the current node closes the first group, the depot the second.  Each is written by
+    // the lane that updated that node's avg/sd above (same-thread store -> load ordering).
+    if (lane == (cur & 63)) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+    if (lane == 0) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+    wave_lds_sync();
+
+    float *tout = tile_out + (size_t)r * (knn + depot_knn + 2) * DGL_TILE_STRIDE;
+    float *toutD = tout + (kl + 1) * DGL_TILE_STRIDE;
+    wave_minmax_norm_store(tileL, kl + 1, CVRP_F, DGL_TILE_STRIDE, tout);        // CVRP/CVRPModel.py:299
+    wave_minmax_norm_store(tileD, kd + 1, CVRP_F, DGL_TILE_STRIDE, toutD);       // :301
+    // group flag (:303-304) and padding columns
+    const int ntok = kl + kd + 2;
+    for (int e = lane; e < ntok * (DGL_TILE_STRIDE - CVRP_F); e += 64) {
+        const int tk = e / (DGL_TILE_STRIDE - CVRP_F), c = CVRP_F + e % (DGL_TILE_STRIDE - CVRP_F);
+        tout[tk * DGL_TILE_STRIDE + c] = (c == CVRP_F && tk > kl) ? 1.0f : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------- dense state (API parity)
+__global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__restrict__ out) {
+    const int r = blockIdx.y, N = st.N, M = N + 1;
+    const int b = r / st.rows_per_instance;
+    CvrpRowCtx cx;
+    cx.xyb = st.xy + (size_t)b * M * 2;
+    cx.demb = st.demand + (size_t)b * M;
+    cx.rowM = (size_t)r * M;
+    const int cur = st.nodes[(size_t)r * N + (t - 1)];
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        float f[CVRP_F];
+        cvrp_features(st, cx, j, f);
+        float *o = out + (cx.rowM + j) * CVRP_F;
+#pragma unroll
+        for (int c = 0; c < CVRP_F; ++c) o[c] = f[c];
+    }
+}
+
+// -------------------------------------------------------------------- route length
+// CVRP/CVRPEnv.py:951-993: position p contributes |cur - mid| + |prev - mid'| with mid = depot if
+// the move goes via the depot else cur itself, mid' = mid except depot at p = 0; prev of p = 0 is
+// the last customer (closing leg).  Segments sqrt(fl(dx^2)+fl(dy^2)), summed in binary64.
+__device__ __forceinline__ float seg_len(const float *xy, int a, int c) {
+    const float dx = __fsub_rn(xy[2 * a], xy[2 * c]), dy = __fsub_rn(xy[2 * a + 1], xy[2 * c + 1]);
+    return sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+}
+__global__ __launch_bounds__(256) void cvrp_length_kernel(dgl_cvrp_state_t st, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= st.R) return;
+    const int N = st.N, M = N + 1;
+    const float *xyb = st.xy + (size_t)(r / st.rows_per_instance) * M * 2;
+    const int32_t *nodes = st.nodes + (size_t)r * N;
+    const int8_t *flags = st.flags + (size_t)r * N;
+    double s = 0.0;
+    for (int p = lane; p < N; p += 64) {
+        const int cur = nodes[p], prev = nodes[p == 0 ? N - 1 : p - 1];
+        const int mid = flags[p] ? 0 : cur;
+        const int mid2 = p == 0 ? 0 : mid;
+        s += (double)seg_len(xyb, cur, mid) + (double)seg_len(xyb, prev, mid2);
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) out[r] = (float)s;
+}
+
+// ------------------------------------------------------------------ beam permutation
+__global__ __launch_bounds__(256) void cvrp_permute_kernel(dgl_cvrp_state_t src, dgl_cvrp_state_t dst,
+                                                          const int32_t *__restrict__ prev_k, int beam, int t) {
+    const int r = blockIdx.x, g = r / beam, sr = g * beam + prev_k[r];
+    const int N = src.N, M = N + 1, W = (M + 63) / 64;
+    const size_t so = (size_t)sr * M, d0 = (size_t)r * M;
+    for (int j = threadIdx.x; j < M; j += blockDim.x) {
+        dst.avg[d0 + j] = src.avg[so + j];
+        dst.sd[d0 + j] = src.sd[so + j];
+    }
+    for (int p = threadIdx.x; p < t; p += blockDim.x) {
+        dst.nodes[(size_t)r * N + p] = src.nodes[(size_t)sr * N + p];
+        dst.flags[(size_t)r * N + p] = src.flags[(size_t)sr * N + p];
+    }
+    for (int w = threadIdx.x; w < W; w += blockDim.x) dst.visited[(size_t)r * W + w] = src.visited[(size_t)sr * W + w];
+    if (threadIdx.x == 0) dst.capacity[r] = src.capacity[sr];
+}
+
+// ------------------------------------------------------------------------ launchers
+static int check_cvrp_state(const dgl_cvrp_state_t *st) {
+    DGL_CHECK_ARG(st != nullptr, "state is NULL");
+    DGL_CHECK_ARG(st->B > 0 && st->N > 1 && st->rows_per_instance > 0, "bad sizes B=%d N=%d rows_per_instance=%d",
+                  st->B, st->N, st->rows_per_instance);
+    DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
+    DGL_CHECK_ARG(st->xy && st->demand && st->avg && st->sd && st->capacity && st->visited && st->nodes && st->flags,
+                  "NULL state buffer");
+    return DGL_OK;
+}
+
+extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    const int M = st->N + 1;
+    size_t lds = (size_t)M * 2 * sizeof(float);
+    DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19199)", st->N);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)cvrp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 3) / 4, st->B), dim3(256), lds, (hipStream_t)stream, *st);
+    DGL_CHECK_LAUNCH("dgl_cvrp_reset");
+    return DGL_OK;
+}
+
+extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn,
+                             int32_t depot_knn, int32_t *idx_last_out, int32_t *idx_depot_out,
+                             uint8_t *infeasible_out, float *tile_out, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    DGL_CHECK_ARG(action != nullptr, "action is NULL");
+    DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
+    const bool want = idx_last_out != nullptr;
+    DGL_CHECK_ARG(want == (idx_depot_out != nullptr) && want == (infeasible_out != nullptr) && want == (tile_out != nullptr),
+                  "idx_last_out, idx_depot_out, infeasible_out and tile_out must all be given or all be NULL");
+    DGL_CHECK_ARG(!want || (knn >= 1 && depot_knn >= 1), "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
+    if (!want) knn = depot_knn = 1;
+    const int M = st->N + 1;
+    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 64;
+    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
+    if (lds4 <= 64 * 1024) {
+        hipLaunchKernelGGL(cvrp_step_kernel<4>, dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream, *st, action,
+                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
+    } else {
+        size_t lds1 = (size_t)per_wave * sizeof(float);
+        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
+                      depot_knn, lds1);
+        if (lds1 > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds1);
+        hipLaunchKernelGGL(cvrp_step_kernel<1>, dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action, t, knn,
+                           depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
+    }
+    DGL_CHECK_LAUNCH("dgl_cvrp_step");
+    return DGL_OK;
+}
+
+extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
+    DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
+    dim3 grid(min((st->N + 256) / 256, 64), st->R);
+    hipLaunchKernelGGL(cvrp_state_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    DGL_CHECK_LAUNCH("dgl_cvrp_state_data");
+    return DGL_OK;
+}
+
+extern "C" int dgl_cvrp_route_length(const dgl_cvrp_state_t *st, float *length_out, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    DGL_CHECK_ARG(length_out != nullptr, "length_out is NULL");
+    hipLaunchKernelGGL(cvrp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
+    DGL_CHECK_LAUNCH("dgl_cvrp_route_length");
+    return DGL_OK;
+}
+
+extern "C" int dgl_cvrp_permute(const dgl_cvrp_state_t *src, const dgl_cvrp_state_t *dst, const int32_t *prev_k,
+                                int32_t beam, int32_t t, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(src)) return e;
+    if (int e = check_cvrp_state(dst)) return e;
+    DGL_CHECK_ARG(prev_k != nullptr && beam >= 1, "bad prev_k/beam");
+    DGL_CHECK_ARG(src->R == dst->R && src->N == dst->N && src->R % beam == 0, "src/dst shapes differ or R %% beam != 0");
+    DGL_CHECK_ARG(src->avg != dst->avg && src->sd != dst->sd && src->nodes != dst->nodes && src->visited != dst->visited &&
+                      src->flags != dst->flags && src->capacity != dst->capacity,
+                  "src and dst must be distinct buffers");
+    hipLaunchKernelGGL(cvrp_permute_kernel, dim3(src->R), dim3(256), 0, (hipStream_t)stream, *src, *dst, prev_k, beam, t);
+    DGL_CHECK_LAUNCH("dgl_cvrp_permute");
+    return DGL_OK;
+}

@@ -454,7 +454,7 @@ static int launch_policy(const float *P, const dgl_policy_io_t *io, hipStream_t 
     const size_t lds = (size_t)(2 * ROWS * 32 * LDX + 4 * ROWS * 32) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipFuncSetAttribute((const void *)policy_kernel<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)policy_kernel<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     hipLaunchKernelGGL(policy_kernel<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);

@@ -8,45 +8,14 @@
 // arithmetic wherever they are needed.
 #include "common.h"
 #include "select.h"
+#include "state_common.h"
 
 #define TSP_F 7
 
 // --------------------------------------------------------------------------- reset
-// grid: (ceil(N / 4), B), block 256 = 4 waves, wave w handles node i = 4*blockIdx.x + w.
-// The instance's coordinates are staged once per block in LDS.
+// grid: (ceil(N / 4), B), block 256 = 4 waves (see dgl_reset_rows in state_common.h)
 __global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
-    extern __shared__ float lds_xy[];   // [N][2]
-    const int b = blockIdx.y, N = st.N;
-    const float *xyb = st.xy + (size_t)b * N * 2;
-    for (int e = threadIdx.x; e < 2 * N; e += blockDim.x) lds_xy[e] = xyb[e];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i < N) {
-        const float xi = lds_xy[2 * i], yi = lds_xy[2 * i + 1], ni = dgl_sqnorm(xi, yi);
-        double s = 0.0, q = 0.0;
-        for (int j = lane; j < N; j += 64) {
-            float xj = lds_xy[2 * j], yj = lds_xy[2 * j + 1];
-            double d = (double)dgl_chain_dist(xi, yi, ni, xj, yj, dgl_sqnorm(xj, yj));
-            s += d;
-            q = fma(d, d, q);
-        }
-        s = wave_sum_f64(s);
-        q = wave_sum_f64(q);
-        double mean = s / N;
-        double var = q / N - mean * mean;
-        float favg = (float)mean, fsd = (float)sqrt(var > 0.0 ? var : 0.0);
-        for (int p = lane; p < st.rows_per_instance; p += 64) {
-            size_t r = (size_t)b * st.rows_per_instance + p;
-            st.avg[r * N + i] = favg;
-            st.sd[r * N + i] = fsd;
-        }
-    }
-    // clear the visited words of this instance's rows (block x == 0 only)
-    if (blockIdx.x == 0) {
-        const int W = (N + 63) / 64;
-        size_t base = (size_t)b * st.rows_per_instance * W;
-        for (int e = threadIdx.x; e < st.rows_per_instance * W; e += blockDim.x) st.visited[base + e] = 0ull;
-    }
+    dgl_reset_rows(st.xy, st.N, st.rows_per_instance, st.avg, st.sd, st.visited);
 }
 
 // ---------------------------------------------------------------------------- step
@@ -217,7 +186,7 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     size_t lds = (size_t)st->N * 2 * sizeof(float);
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
     if (lds > 48 * 1024)
-        hipFuncSetAttribute((const void *)tsp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)tsp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((st->N + 3) / 4, st->B);
     hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_tsp_reset");
@@ -241,7 +210,7 @@ extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, 
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
         if (lds1 > 48 * 1024)
-            hipFuncSetAttribute((const void *)tsp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         hipLaunchKernelGGL(tsp_step_kernel<1>, dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, selected, t,
                            knn, idx_out, tile_out, per_wave);
     }

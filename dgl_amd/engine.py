@@ -159,5 +159,119 @@ class TspEngine:
 
 
 class CvrpEngine:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("CVRP engine: work in progress")
+    """Compact CVRP state.  ``xy`` [B][N+1][2] (depot first), ``demand`` [B][N+1] (depot 0,
+    already divided by the vehicle capacity)."""
+
+    def __init__(self, xy: torch.Tensor, demand: torch.Tensor, rows_per_instance: int, knn: int, depot_knn: int):
+        assert xy.is_cuda and xy.dtype == torch.float32 and xy.dim() == 3 and xy.shape[2] == 2
+        assert demand.is_cuda and demand.dtype == torch.float32 and demand.shape == xy.shape[:2]
+        self.lib = _lib.load()
+        self.xy, self.demand = xy.contiguous(), demand.contiguous()
+        self.B, self.M = xy.shape[0], xy.shape[1]
+        self.N = self.M - 1
+        self.rpi = rows_per_instance
+        self.R = self.B * rows_per_instance
+        self.knn, self.depot_knn = knn, depot_knn
+        dev = xy.device
+        self.device = dev
+        R = self.R
+        self.W = (self.M + 63) // 64
+        self.ntok_max = knn + depot_knn + 2
+        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]
+        self.cur = 0
+        self.idx_last = torch.empty(R, knn, dtype=torch.int32, device=dev)
+        self.idx_dep = torch.empty(R, depot_knn, dtype=torch.int32, device=dev)
+        self.infeasible = torch.zeros(R, knn, dtype=torch.uint8, device=dev)
+        self.tile = torch.zeros(R, self.ntok_max * TILE_STRIDE, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self.prob = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
+        self.length = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def _alloc_state(self):
+        R, N, M, dev = self.R, self.N, self.M, self.device
+        t = dict(avg=torch.empty(R, M, dtype=torch.float32, device=dev),
+                 sd=torch.empty(R, M, dtype=torch.float32, device=dev),
+                 capacity=torch.ones(R, dtype=torch.float32, device=dev),
+                 visited=torch.zeros(R, self.W, dtype=torch.int64, device=dev),
+                 nodes=torch.zeros(R, N, dtype=torch.int32, device=dev),
+                 flags=torch.zeros(R, N, dtype=torch.int8, device=dev))
+        t["struct"] = _lib.CvrpState(self.B, N, self.rpi, R, ptr(self.xy), ptr(self.demand), ptr(t["avg"]),
+                                     ptr(t["sd"]), ptr(t["capacity"]), ptr(t["visited"]), ptr(t["nodes"]),
+                                     ptr(t["flags"]))
+        return t
+
+    @property
+    def state(self):
+        return self.bufs[self.cur]
+
+    def reset(self) -> None:
+        check(self.lib.dgl_cvrp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_cvrp_reset")
+        self.t = 0
+
+    def step(self, action: torch.Tensor, want_knn: bool = True) -> None:
+        assert action.dtype == torch.int32 and action.is_cuda and action.numel() == self.R
+        self.t += 1
+        more = want_knn and self.t < self.N
+        check(self.lib.dgl_cvrp_step(ctypes.byref(self.state["struct"]), ptr(action), self.t, self.knn, self.depot_knn,
+                                     ptr(self.idx_last) if more else 0, ptr(self.idx_dep) if more else 0,
+                                     ptr(self.infeasible) if more else 0, ptr(self.tile) if more else 0,
+                                     stream_ptr()), "dgl_cvrp_step")
+
+    @property
+    def kd(self) -> int:
+        return min(self.depot_knn, self.N - self.t)
+
+    @property
+    def kl(self) -> int:
+        return min(self.knn, self.kd)
+
+    def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
+        kl, kd = self.kl, self.kd
+        return _lib.PolicyIO(PROBLEM_CVRP, self.R, kl + kd + 2, kl, self.N, self.knn, self.depot_knn,
+                             self.ntok_max * TILE_STRIDE, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
+                             ptr(self.infeasible),
+                             ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
+                             ptr(self.selected) if want_selected else 0)
+
+    def forward(self, policy: PackedPolicy, **kw) -> None:
+        io = self.policy_io(**kw)
+        check(self.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+
+    def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        A = 2 * (self.N + 1)
+        if out is None:
+            out = torch.empty(self.R, A, dtype=torch.float32, device=self.device)
+        io = self.policy_io()
+        check(self.lib.dgl_policy_scatter_probs(ctypes.byref(io), ptr(self.prob), ptr(out), A, stream_ptr()),
+              "dgl_policy_scatter_probs")
+        return out
+
+    def permute(self, prev_k: torch.Tensor, beam: int) -> None:
+        assert len(self.bufs) == 2 and prev_k.dtype == torch.int32
+        src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
+        check(self.lib.dgl_cvrp_permute(ctypes.byref(src["struct"]), ctypes.byref(dst["struct"]), ptr(prev_k), beam,
+                                        self.t, stream_ptr()), "dgl_cvrp_permute")
+        self.cur = 1 - self.cur
+
+    def data(self) -> torch.Tensor:
+        out = torch.empty(self.R, self.M, 8, dtype=torch.float32, device=self.device)
+        check(self.lib.dgl_cvrp_state_data(ctypes.byref(self.state["struct"]), self.t, ptr(out), stream_ptr()),
+              "dgl_cvrp_state_data")
+        return out
+
+    def route_length(self) -> torch.Tensor:
+        check(self.lib.dgl_cvrp_route_length(ctypes.byref(self.state["struct"]), ptr(self.length), stream_ptr()),
+              "dgl_cvrp_route_length")
+        return self.length
+
+    tour_length = route_length
+
+    def greedy_rollout(self, policy: PackedPolicy, start_action: torch.Tensor) -> torch.Tensor:
+        self.reset()
+        self.step(start_action)
+        while self.t < self.N:
+            self.forward(policy, want_logits=False, want_prob=False)
+            self.step(self.selected)
+        return self.route_length()

@@ -1,0 +1,190 @@
+"""GPU parity tests of the CVRP path: HIP kernels (through the C ABI) vs the golden vectors
+captured from the reference and vs the plain-C oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(case, device, rpi=1):
+    from dgl_amd.engine import CvrpEngine
+    xy = np.concatenate([case["depot_xy"][:, None, :], case["node_xy"]], axis=1)
+    dem = np.concatenate([np.zeros((xy.shape[0], 1), np.float32), case["demand"]], axis=1)
+    return CvrpEngine(torch.from_numpy(xy).to(device), torch.from_numpy(dem).to(device), rpi,
+                      int(case["meta/knn"]), int(case["meta/depot_knn"]))
+
+
+def _actions(case):
+    N = case["node_xy"].shape[1]
+    return case["nodes"].astype(np.int32) + (N + 1) * case["flags"].astype(np.int32)
+
+
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20"])
+def test_reset_matches_golden(name, device):
+    case, _ = load_golden(name)
+    eng = _engine(case, device)
+    eng.reset()
+    np.testing.assert_allclose(eng.state["avg"].cpu().numpy(), case["avg0"], rtol=3e-7)
+    np.testing.assert_allclose(eng.state["sd"].cpu().numpy(), case["std0"], rtol=3e-7)
+    assert (eng.state["capacity"].cpu().numpy() == 1.0).all()
+
+
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n100_b64_nn"])
+def test_teacher_forced_steps_match_golden(name, device):
+    from dgl_amd._lib import PROBLEM_CVRP, TILE_STRIDE
+    from dgl_amd.engine import PackedPolicy
+    case, weights = load_golden(name)
+    if int(case["meta/knn"]) + int(case["meta/depot_knn"]) + 2 > 32:
+        pytest.skip("more than 32 tokens per row")
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_CVRP, device)
+    act = torch.from_numpy(_actions(case)).to(device)
+    N = eng.N
+    eng.reset()
+    max_logit_err = max_tile_err = max_cap_err = tail_logit_err = 0.0
+    tile_errs = []
+    agree = total = 0
+    for t in range(1, N):
+        eng.step(act[:, t - 1].contiguous())
+        kl, kd = eng.kl, eng.kd
+        il, idp = eng.idx_last.cpu().numpy(), eng.idx_dep.cpu().numpy()
+        assert np.array_equal(il[:, :kl], case["idx_last"][t - 1][:, :kl]), t
+        assert np.array_equal(idp[:, :kd], case["idx_dep"][t - 1][:, :kd]), t
+        assert (il[:, kl:] == -1).all() and (idp[:, kd:] == -1).all()
+        eng.forward(pol)
+        n = kl + kd + 2
+        if "capacity" in case:
+            cap = eng.state["capacity"].cpu().numpy()
+            max_cap_err = max(max_cap_err, float(np.abs(cap - case["capacity"][t - 1]).max()))
+        if "logits" in case:
+            # the reference's decoder orders tokens [last', knn.., depot', depot-knn..]; ours keeps
+            # the encoder order [knn.., last, depot-knn.., depot]
+            g = case["logits"][t - 1][:, :n]
+            g_enc = np.concatenate([g[:, 1:kl + 1], g[:, 0:1], g[:, kl + 2:n], g[:, kl + 1:kl + 2]], axis=1)
+            logits = eng.logits.cpu().numpy()[:, :n]
+            scale = np.abs(g_enc).max(axis=1, keepdims=True)
+            err = float((np.abs(logits - g_enc) / scale).max())
+            # The avg/sd recurrences amplify a 1-ulp difference by ~N/u (u nodes left), and with <= 3
+            # nodes left the running std is analytically ~0, i.e. the reference's own value is rounding
+            # noise that min-max normalisation over 2-4 tokens blows up to 0/1.  The 1e-3 bound is
+            # therefore asserted while more than 8 nodes are left; the tail is reported.
+            if N - t > 8:
+                max_logit_err = max(max_logit_err, err)
+            else:
+                tail_logit_err = max(tail_logit_err, err)
+        if "tile" in case:
+            tile = eng.tile.cpu().numpy().reshape(eng.R, -1, TILE_STRIDE)[:, :n, :9]
+            gt = case["tile"][t - 1][:, :n * 9].reshape(eng.R, n, 9)
+            if N - t > 8:
+                max_tile_err = max(max_tile_err, float(np.abs(tile - gt).max()))
+                tile_errs.append(np.abs(tile - gt).ravel())
+        sel = eng.selected.cpu().numpy()
+        agree += int((sel == _actions(case)[:, t]).sum())
+        total += eng.R
+    print(f"{name}: max rel logit err {max_logit_err:.2e} (last 8 steps {tail_logit_err:.2e}), max tile err {max_tile_err:.2e}, capacity err "
+          f"{max_cap_err:.1e}, greedy pick agreement {agree}/{total}")
+    assert max_logit_err < 1e-3
+    assert max_cap_err == 0.0
+    if tile_errs:
+        errs = np.concatenate(tile_errs)
+        assert np.quantile(errs, 0.999) < 2e-5
+        assert max_tile_err < 5e-3
+
+
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8"])
+def test_state_data_matches_golden(name, device):
+    case, _ = load_golden(name)
+    eng = _engine(case, device)
+    act = torch.from_numpy(_actions(case)).to(device)
+    eng.reset()
+    snaps = sorted(int(k[4:].split("/")[0]) for k in case if k.startswith("snap") and k.endswith("/data"))
+    for t in range(1, eng.N):
+        eng.step(act[:, t - 1].contiguous())
+        if t in snaps:
+            data = eng.data().cpu().numpy()
+            g = case[f"snap{t}/data"]
+            tol = 4e-7 * eng.M / (eng.M - t)
+            np.testing.assert_allclose(data[:, :, :4], g[:, :, :4], rtol=2e-7, atol=1e-7)
+            np.testing.assert_allclose(data[:, :, 4:6], g[:, :, 4:6], rtol=tol, atol=tol)
+            np.testing.assert_allclose(data[:, :, 6:], g[:, :, 6:], rtol=1e-5, atol=1e-6)
+            # the capacity snapshot is taken after env.step, i.e. before the model nudges it
+            gcap = case[f"snap{t}/capacity"]
+            cap = eng.state["capacity"].cpu().numpy()
+            assert np.all((cap == gcap) | ((gcap < 1e-5) & (np.abs(cap - gcap - 1e-7) < 1e-9)))
+
+
+def test_recurrences_bit_exact_vs_c_oracle(device):
+    """Synthetic instance, random feasible actions: state arithmetic and both neighbourhoods must be
+    bit-identical to the plain-C oracle."""
+    from dgl_amd.engine import CvrpEngine
+    from oracle import cref
+    lib = cref.load()
+    rng = np.random.default_rng(3)
+    B, N, knn, kd = 2, 150, 15, 20
+    M = N + 1
+    xy = rng.random((B, M, 2), dtype=np.float32)
+    dem = np.concatenate([np.zeros((B, 1), np.float32), (rng.integers(1, 200, (B, N)) / 500.0).astype(np.float32)], 1)
+    eng = CvrpEngine(torch.from_numpy(xy).to(device), torch.from_numpy(dem).to(device), 1, knn, kd)
+    eng.reset()
+    avg, sd = eng.state["avg"].cpu().numpy().copy(), eng.state["sd"].cpu().numpy().copy()
+    cap = np.ones(B, np.float32)
+    visited = np.zeros((B, M), np.uint8)
+    order = np.stack([rng.permutation(N) + 1 for _ in range(B)])
+    for t in range(1, N):
+        acts = np.zeros(B, np.int32)
+        for b in range(B):
+            node = int(order[b, t - 1])
+            via = t == 1 or cap[b] + 1e-6 < dem[b, node]
+            acts[b] = node + (M if via else 0)
+        eng.step(torch.from_numpy(acts).to(device))
+        gavg, gsd = eng.state["avg"].cpu().numpy(), eng.state["sd"].cpu().numpy()
+        gcap = eng.state["capacity"].cpu().numpy()
+        il, idp = eng.idx_last.cpu().numpy(), eng.idx_dep.cpu().numpy()
+        inf = eng.infeasible.cpu().numpy()
+        for b in range(B):
+            c = ctypes.c_float(cap[b])
+            infeas = np.zeros(M, np.uint8)
+            flag = ctypes.c_int(0)
+            node = lib.dglref_cvrp_apply(N, int(acts[b]), dem[b], ctypes.byref(c), infeas, ctypes.byref(flag))
+            cap[b] = c.value
+            visited[b, node] = 1
+            d = np.empty(M, np.float32)
+            lib.dglref_step_features(np.ascontiguousarray(xy[b]), M, node, M - t, 1, avg[b], sd[b], d)
+            ril, rid = np.full(knn, -1, np.int32), np.full(kd, -1, np.int32)
+            klc = ctypes.c_int(0)
+            kdd = lib.dglref_cvrp_knn(np.ascontiguousarray(xy[b]), N, node, visited[b], knn, kd, ril, rid, ctypes.byref(klc))
+            assert np.array_equal(il[b], ril) and np.array_equal(idp[b], rid), (t, b)
+            assert np.array_equal(inf[b, :klc.value], infeas[ril[:klc.value]]), (t, b)
+            if cap[b] < 1e-5:
+                cap[b] = np.float32(cap[b] + np.float32(1e-7))
+        assert np.array_equal(gavg, avg) and np.array_equal(gsd, sd), t
+        assert np.array_equal(gcap, cap), t
+        avg, sd = gavg.copy(), gsd.copy()
+
+
+@pytest.mark.parametrize("name,min_identical", [("cvrp_n100_b64_nn", 0.9), ("cvrp_n1000_b4_nn", 0.5),
+                                                ("cvrp_n100_b256_nn_tours", 0.99)])
+def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
+    from dgl_amd._lib import PROBLEM_CVRP
+    from dgl_amd.engine import PackedPolicy
+    case, weights = load_golden(name)
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_CVRP, device)
+    start = torch.from_numpy(case["start"]).to(device=device, dtype=torch.int32).repeat(eng.B) + 2 + eng.N
+    length = eng.greedy_rollout(pol, start).cpu().numpy()
+    nodes, flags = eng.state["nodes"].cpu().numpy(), eng.state["flags"].cpu().numpy()
+    for r in range(min(eng.R, 16)):
+        assert sorted(nodes[r].tolist()) == list(range(1, eng.N + 1))
+    same = (nodes == case["nodes"]).all(axis=1) & (flags == case["flags"]).all(axis=1)
+    frac = same.mean()
+    rel = abs(length.mean() - case["length"].mean()) / case["length"].mean()
+    print(f"{name}: identical routes {int(same.sum())}/{eng.R} ({100 * frac:.2f} %), mean length "
+          f"{length.mean():.6f} vs {case['length'].mean():.6f} (rel diff {rel:.2e})")
+    assert frac >= min_identical
+    assert rel < 1e-4
+    np.testing.assert_allclose(length[same], case["length"][same], rtol=3e-6)
