@@ -53,12 +53,15 @@ SIGNATURES = {
     "dgl_last_error_string": (c_char_p, []),
     "dgl_tsp_reset": (c_int32, [POINTER(TspState), c_void_p]),
     "dgl_tsp_step": (c_int32, [POINTER(TspState), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "dgl_tsp_knn": (c_int32, [POINTER(TspState), c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dgl_tsp_state_data": (c_int32, [POINTER(TspState), c_int32, c_void_p, c_void_p]),
     "dgl_tsp_tour_length": (c_int32, [POINTER(TspState), c_void_p, c_void_p]),
     "dgl_tsp_permute": (c_int32, [POINTER(TspState), POINTER(TspState), c_void_p, c_int32, c_int32, c_void_p]),
     "dgl_cvrp_reset": (c_int32, [POINTER(CvrpState), c_void_p]),
     "dgl_cvrp_step": (c_int32, [POINTER(CvrpState), c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "dgl_cvrp_knn": (c_int32, [POINTER(CvrpState), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
     "dgl_cvrp_state_data": (c_int32, [POINTER(CvrpState), c_int32, c_void_p, c_void_p]),
     "dgl_cvrp_route_length": (c_int32, [POINTER(CvrpState), c_void_p, c_void_p]),
     "dgl_cvrp_permute": (c_int32, [POINTER(CvrpState), POINTER(CvrpState), c_void_p, c_int32, c_int32, c_void_p]),

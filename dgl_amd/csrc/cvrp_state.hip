@@ -39,7 +39,7 @@ __device__ __forceinline__ void cvrp_features(const dgl_cvrp_state_t &st, const 
     f[7] = __fdiv_rn(__fsub_rn(cx.x0, x), den);
 }
 
-template <int WAVES>
+template <int WAVES, bool UPDATE>
 __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
@@ -63,12 +63,12 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     cx.rowM = (size_t)r * M;
 
     // ---- action decoding, capacity (CVRP/CVRPEnv.py:612-631)
-    const int act = action[r];
+    const int act = UPDATE ? action[r] : 0;
     const bool via = act > N;
-    const int cur = via ? act - (N + 1) : act;
+    const int cur = UPDATE ? (via ? act - (N + 1) : act) : st.nodes[(size_t)r * N + (t - 1)];
     const float dem_cur = cx.demb[cur];
     const float cap_old = st.capacity[r];
-    float cap = via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur);
+    float cap = !UPDATE ? cap_old : (via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur));
     const float cap_eps = __fadd_rn(cap, 0.000001f);          // feasibility uses the un-nudged capacity
 
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
@@ -84,14 +84,16 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         const unsigned long long word = vis[j0 >> 6];
         if (j < M) {
             const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-            const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);
-            const float a0 = st.avg[cx.rowM + j], s0 = st.sd[cx.rowM + j];
-            const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);            // :711
-            const float e = __fsub_rn(dcol, a0);
-            float item = __fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf);   // :733
-            if (item < 0.0f) item = 0.0f;                                                     // :735-736
-            st.avg[cx.rowM + j] = a1;
-            st.sd[cx.rowM + j] = sqrtf(item);
+            if (UPDATE) {
+                const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);
+                const float a0 = st.avg[cx.rowM + j], s0 = st.sd[cx.rowM + j];
+                const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);            // :711
+                const float e = __fsub_rn(dcol, a0);
+                float item = __fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf);   // :733
+                if (item < 0.0f) item = 0.0f;                                                     // :735-736
+                st.avg[cx.rowM + j] = a1;
+                st.sd[cx.rowM + j] = sqrtf(item);
+            }
             if (want_knn) {
                 const bool out = ((word >> (j & 63)) & 1ull) || (j == cur) || (j == 0);
                 const float kl = out ? INFINITY : dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
@@ -110,9 +112,11 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     }
     if (lane == 0) {
         st.capacity[r] = cap;
-        st.nodes[(size_t)r * N + (t - 1)] = cur;
-        st.flags[(size_t)r * N + (t - 1)] = via ? 1 : 0;
-        vis[cur >> 6] |= 1ull << (cur & 63);
+        if (UPDATE) {
+            st.nodes[(size_t)r * N + (t - 1)] = cur;
+            st.flags[(size_t)r * N + (t - 1)] = via ? 1 : 0;
+            vis[cur >> 6] |= 1ull << (cur & 63);
+        }
     }
     if (!want_knn) return;
 
@@ -249,6 +253,31 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     return DGL_OK;
 }
 
+template <bool UPDATE>
+static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                            int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                            dgl_stream_t stream, const char *what) {
+    const int M = st->N + 1;
+    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 64;
+    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
+    if (lds4 <= 64 * 1024) {
+        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
+                           *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                           per_wave);
+    } else {
+        size_t lds1 = (size_t)per_wave * sizeof(float);
+        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
+                      depot_knn, lds1);
+        if (lds1 > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1, UPDATE>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
+                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
+    }
+    DGL_CHECK_LAUNCH(what);
+    return DGL_OK;
+}
+
 extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn,
                              int32_t depot_knn, int32_t *idx_last_out, int32_t *idx_depot_out,
                              uint8_t *infeasible_out, float *tile_out, dgl_stream_t stream) {
@@ -260,24 +289,19 @@ extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, 
                   "idx_last_out, idx_depot_out, infeasible_out and tile_out must all be given or all be NULL");
     DGL_CHECK_ARG(!want || (knn >= 1 && depot_knn >= 1), "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
     if (!want) knn = depot_knn = 1;
-    const int M = st->N + 1;
-    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 64;
-    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    if (lds4 <= 64 * 1024) {
-        hipLaunchKernelGGL(cvrp_step_kernel<4>, dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream, *st, action,
-                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
-    } else {
-        size_t lds1 = (size_t)per_wave * sizeof(float);
-        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
-                      depot_knn, lds1);
-        if (lds1 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds1);
-        hipLaunchKernelGGL(cvrp_step_kernel<1>, dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action, t, knn,
-                           depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
-    }
-    DGL_CHECK_LAUNCH("dgl_cvrp_step");
-    return DGL_OK;
+    return launch_cvrp_step<true>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                                  stream, "dgl_cvrp_step");
+}
+
+extern "C" int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, int32_t depot_knn,
+                            int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                            dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    DGL_CHECK_ARG(t >= 1 && t < st->N, "t=%d outside [1,N-1=%d]", t, st->N - 1);
+    DGL_CHECK_ARG(idx_last_out && idx_depot_out && infeasible_out && tile_out, "NULL output");
+    DGL_CHECK_ARG(knn >= 1 && depot_knn >= 1, "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
+    return launch_cvrp_step<false>(st, nullptr, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                                   stream, "dgl_cvrp_knn");
 }
 
 extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream) {

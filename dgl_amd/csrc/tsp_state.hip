@@ -39,7 +39,7 @@ __device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const Ts
     f[6] = __fdiv_rn(__fsub_rn(cx.xs, x), den);
 }
 
-template <int WAVES>
+template <int WAVES, bool UPDATE>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
                                                              float *__restrict__ tile_out, int lds_per_wave) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     TspRowCtx cx;
     cx.xyb = st.xy + (size_t)b * N * 2;
     cx.rowN = (size_t)r * N;
-    const int cur = selected[r];
+    const int cur = UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)];
     const int start = (t == 1) ? cur : st.tour[cx.rowN];
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
@@ -71,14 +71,16 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         const unsigned long long word = vis[j0 >> 6];      // same address for the whole wave
         if (j < N) {
             const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-            const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);    // dis[j][cur]
-            const float a0 = st.avg[cx.rowN + j], s0 = st.sd[cx.rowN + j];
-            // TSP/TSPEnv.py:386, 408-409
-            const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);
-            const float e = __fsub_rn(dcol, a0);
-            const float s1 = sqrtf(__fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf));
-            st.avg[cx.rowN + j] = a1;
-            st.sd[cx.rowN + j] = s1;
+            if (UPDATE) {
+                const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);    // dis[j][cur]
+                const float a0 = st.avg[cx.rowN + j], s0 = st.sd[cx.rowN + j];
+                // TSP/TSPEnv.py:386, 408-409
+                const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);
+                const float e = __fsub_rn(dcol, a0);
+                const float s1 = sqrtf(__fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf));
+                st.avg[cx.rowN + j] = a1;
+                st.sd[cx.rowN + j] = s1;
+            }
             if (want_knn) {
                 const float drow = dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
                 const bool visited = ((word >> (j & 63)) & 1ull) || (j == cur);
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
             }
         }
     }
-    if (lane == 0) {
+    if (UPDATE && lane == 0) {
         st.tour[cx.rowN + (t - 1)] = cur;
         vis[cur >> 6] |= 1ull << (cur & 63);
     }
@@ -193,6 +195,27 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     return DGL_OK;
 }
 
+template <bool UPDATE>
+static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                           float *tile_out, dgl_stream_t stream, const char *what) {
+    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 64;
+    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
+    if (lds4 <= 64 * 1024) {
+        hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
+                           *st, selected, t, knn, idx_out, tile_out, per_wave);
+    } else {
+        size_t lds1 = (size_t)per_wave * sizeof(float);
+        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
+        if (lds1 > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1, UPDATE>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipLaunchKernelGGL((tsp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
+                           selected, t, knn, idx_out, tile_out, per_wave);
+    }
+    DGL_CHECK_LAUNCH(what);
+    return DGL_OK;
+}
+
 extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
                             int32_t *idx_out, float *tile_out, dgl_stream_t stream) {
     if (int e = check_tsp_state(st)) return e;
@@ -201,21 +224,15 @@ extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, 
     DGL_CHECK_ARG((idx_out == nullptr) == (tile_out == nullptr), "idx_out and tile_out must both be given or both be NULL");
     DGL_CHECK_ARG(idx_out == nullptr || knn >= 1, "knn=%d must be >= 1", knn);
     if (idx_out == nullptr) knn = 1;
-    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 64;
-    size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    if (lds4 <= 64 * 1024) {
-        hipLaunchKernelGGL(tsp_step_kernel<4>, dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream, *st,
-                           selected, t, knn, idx_out, tile_out, per_wave);
-    } else {
-        size_t lds1 = (size_t)per_wave * sizeof(float);
-        DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
-        if (lds1 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipLaunchKernelGGL(tsp_step_kernel<1>, dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, selected, t,
-                           knn, idx_out, tile_out, per_wave);
-    }
-    DGL_CHECK_LAUNCH("dgl_tsp_step");
-    return DGL_OK;
+    return launch_tsp_step<true>(st, selected, t, knn, idx_out, tile_out, stream, "dgl_tsp_step");
+}
+
+extern "C" int dgl_tsp_knn(const dgl_tsp_state_t *st, int32_t t, int32_t knn, int32_t *idx_out, float *tile_out,
+                           dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    DGL_CHECK_ARG(t >= 1 && t < st->N, "t=%d outside [1,N-1=%d]", t, st->N - 1);
+    DGL_CHECK_ARG(idx_out != nullptr && tile_out != nullptr && knn >= 1, "idx_out/tile_out NULL or knn=%d < 1", knn);
+    return launch_tsp_step<false>(st, nullptr, t, knn, idx_out, tile_out, stream, "dgl_tsp_knn");
 }
 
 extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream) {

@@ -78,6 +78,25 @@ class TspEngine:
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
         self.t = 0
+        self.tile_t = -1                 # step count the neighbourhood buffers (idx, tile) belong to
+        self._beam_bufs = None
+
+    def set_knn(self, knn: int) -> None:
+        """Change the neighbourhood size (re-allocates the per-step scratch)."""
+        if knn == self.knn:
+            return
+        self.knn = knn
+        self.idx = torch.empty(self.R, knn, dtype=torch.int32, device=self.device)
+        self.tile = torch.zeros(self.R, (knn + 1) * TILE_STRIDE, dtype=torch.float32, device=self.device)
+        self.tile_t = -1
+
+    def ensure_neighbourhood(self) -> None:
+        """Build idx/tile for the current state if the last step did not (dgl_tsp_knn)."""
+        if self.tile_t == self.t:
+            return
+        check(self.lib.dgl_tsp_knn(ctypes.byref(self.state["struct"]), self.t, self.knn, ptr(self.idx), ptr(self.tile),
+                                   stream_ptr()), "dgl_tsp_knn")
+        self.tile_t = self.t
 
     def _alloc_state(self):
         R, N, dev = self.R, self.N, self.device
@@ -97,6 +116,7 @@ class TspEngine:
     def reset(self) -> None:
         check(self.lib.dgl_tsp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_tsp_reset")
         self.t = 0
+        self.tile_t = -1
 
     def step(self, selected: torch.Tensor, want_knn: bool = True) -> None:
         """Apply ``selected`` (int32 [R]) and, unless the tour is complete, build the next neighbourhood."""
@@ -106,6 +126,8 @@ class TspEngine:
         check(self.lib.dgl_tsp_step(ctypes.byref(self.state["struct"]), ptr(selected), self.t, self.knn,
                                     ptr(self.idx) if more else 0, ptr(self.tile) if more else 0, stream_ptr()),
               "dgl_tsp_step")
+        if more:
+            self.tile_t = self.t
 
     @property
     def k(self) -> int:
@@ -157,6 +179,35 @@ class TspEngine:
             self.step(self.selected)
         return self.tour_length()
 
+    def beam_advance(self, scores: torch.Tensor, beam: int, step: int, prev_k: torch.Tensor, action: torch.Tensor):
+        """Beam expansion from the compact per-token probabilities of the last forward()."""
+        io = self.policy_io()
+        check(self.lib.dgl_beam_advance_compact(ctypes.byref(io), ptr(self.prob), ptr(scores), self.R // beam, beam,
+                                                self.N, step, ptr(prev_k), ptr(action), stream_ptr()),
+              "dgl_beam_advance_compact")
+
+    def beam_rollout(self, policy: PackedPolicy, start: torch.Tensor, beam: int) -> torch.Tensor:
+        """Beam-search decode (TSP/TSPTester.py:145-199) on the compact state: per step the policy,
+        the beam expansion over beam*k candidates, the back-pointer permutation and the fused
+        state update; nothing returns to the host."""
+        assert self.rpi % beam == 0 and len(self.bufs) == 2
+        G = self.R // beam
+        dev = self.device
+        scores = torch.zeros(G, beam, dtype=torch.float32, device=dev)
+        prev_k = torch.zeros(G, beam, dtype=torch.int32, device=dev)
+        action = torch.zeros(G, beam, dtype=torch.int32, device=dev)
+        self.reset()
+        self.step(start)
+        step = 1
+        while self.t < self.N:
+            self.forward(policy, want_logits=False, want_selected=False)
+            self.beam_advance(scores, beam, step, prev_k, action)
+            self.permute(prev_k, beam)
+            self.step(action.view(-1))
+            step += 1
+        self.beam_scores = scores
+        return self.tour_length()
+
 
 class CvrpEngine:
     """Compact CVRP state.  ``xy`` [B][N+1][2] (depot first), ``demand`` [B][N+1] (depot 0,
@@ -188,6 +239,29 @@ class CvrpEngine:
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
         self.t = 0
+        self.tile_t = -1
+
+    def set_knn(self, knn: int, depot_knn: int) -> None:
+        if knn == self.knn and depot_knn == self.depot_knn:
+            return
+        self.knn, self.depot_knn = knn, depot_knn
+        R, dev = self.R, self.device
+        self.ntok_max = knn + depot_knn + 2
+        self.idx_last = torch.empty(R, knn, dtype=torch.int32, device=dev)
+        self.idx_dep = torch.empty(R, depot_knn, dtype=torch.int32, device=dev)
+        self.infeasible = torch.zeros(R, knn, dtype=torch.uint8, device=dev)
+        self.tile = torch.zeros(R, self.ntok_max * TILE_STRIDE, dtype=torch.float32, device=dev)
+        self.tile_t = -1
+
+    def ensure_neighbourhood(self) -> None:
+        """Build both neighbourhoods and the tile for the current state if the last step did not
+        (dgl_cvrp_knn; nudges near-zero capacities exactly once per step, like the reference)."""
+        if self.tile_t == self.t:
+            return
+        check(self.lib.dgl_cvrp_knn(ctypes.byref(self.state["struct"]), self.t, self.knn, self.depot_knn,
+                                    ptr(self.idx_last), ptr(self.idx_dep), ptr(self.infeasible), ptr(self.tile),
+                                    stream_ptr()), "dgl_cvrp_knn")
+        self.tile_t = self.t
 
     def _alloc_state(self):
         R, N, M, dev = self.R, self.N, self.M, self.device
@@ -209,6 +283,7 @@ class CvrpEngine:
     def reset(self) -> None:
         check(self.lib.dgl_cvrp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_cvrp_reset")
         self.t = 0
+        self.tile_t = -1
 
     def step(self, action: torch.Tensor, want_knn: bool = True) -> None:
         assert action.dtype == torch.int32 and action.is_cuda and action.numel() == self.R
@@ -218,6 +293,8 @@ class CvrpEngine:
                                      ptr(self.idx_last) if more else 0, ptr(self.idx_dep) if more else 0,
                                      ptr(self.infeasible) if more else 0, ptr(self.tile) if more else 0,
                                      stream_ptr()), "dgl_cvrp_step")
+        if more:
+            self.tile_t = self.t
 
     @property
     def kd(self) -> int:
@@ -274,4 +351,30 @@ class CvrpEngine:
         while self.t < self.N:
             self.forward(policy, want_logits=False, want_prob=False)
             self.step(self.selected)
+        return self.route_length()
+
+    def beam_advance(self, scores: torch.Tensor, beam: int, step: int, prev_k: torch.Tensor, action: torch.Tensor):
+        io = self.policy_io()
+        check(self.lib.dgl_beam_advance_compact(ctypes.byref(io), ptr(self.prob), ptr(scores), self.R // beam, beam,
+                                                2 * (self.N + 1), step, ptr(prev_k), ptr(action), stream_ptr()),
+              "dgl_beam_advance_compact")
+
+    def beam_rollout(self, policy: PackedPolicy, start_action: torch.Tensor, beam: int) -> torch.Tensor:
+        """Beam-search decode (CVRP/CVRPTester.py:147-227) on the compact state."""
+        assert self.rpi % beam == 0 and len(self.bufs) == 2
+        G = self.R // beam
+        dev = self.device
+        scores = torch.zeros(G, beam, dtype=torch.float32, device=dev)
+        prev_k = torch.zeros(G, beam, dtype=torch.int32, device=dev)
+        action = torch.zeros(G, beam, dtype=torch.int32, device=dev)
+        self.reset()
+        self.step(start_action)
+        step = 1
+        while self.t < self.N:
+            self.forward(policy, want_logits=False, want_selected=False)
+            self.beam_advance(scores, beam, step, prev_k, action)
+            self.permute(prev_k, beam)
+            self.step(action.view(-1))
+            step += 1
+        self.beam_scores = scores
         return self.route_length()

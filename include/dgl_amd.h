@@ -90,6 +90,12 @@ DGL_API int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream);
 DGL_API int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
                  int32_t *idx_out, float *tile_out, dgl_stream_t stream);
 
+/* TSPModel.get_knn_state/_get_node/_norm_node alone (TSP/TSPModel.py:50-100,141-172): the
+ * neighbourhood and token tile of the current node tour[r][t-1] from the state as it stands
+ * after t steps, without touching the state.  Same outputs as dgl_tsp_step. */
+DGL_API int dgl_tsp_knn(const dgl_tsp_state_t *st, int32_t t, int32_t knn, int32_t *idx_out, float *tile_out,
+                dgl_stream_t stream);
+
 /* The reference's step_state.data [R][N][7] (TSP/TSPEnv.py:371,393,415,456,475),
  * materialised from the compact state after t >= 1 steps; for API parity and tests. */
 DGL_API int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
@@ -130,6 +136,13 @@ DGL_API int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream);
 DGL_API int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn,
                   int32_t depot_knn, int32_t *idx_last_out, int32_t *idx_depot_out,
                   uint8_t *infeasible_out, float *tile_out, dgl_stream_t stream);
+
+/* CVRPModel.get_knn_state/_norm_node + tile assembly alone (CVRP/CVRPModel.py:51-187,258-309) for
+ * the state after t steps.  Like the reference's get_knn_state it nudges capacities below 1e-5 by
+ * +1e-7 in place (CVRP/CVRPModel.py:164-166), so call it at most once per decode step. */
+DGL_API int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, int32_t depot_knn,
+                 int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                 dgl_stream_t stream);
 
 /* step_state.data [R][M][8] (CVRP/CVRPEnv.py:696,718,746,782,801). */
 DGL_API int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
