@@ -1,0 +1,227 @@
+"""CVRP host side with the reference's interface: CVRPEnv (CVRP/CVRPEnv.py), CVRPModel
+(CVRP/CVRPModel.py).  See dgl_amd.tsp for what differs from the reference's objects."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import PROBLEM_CVRP
+from .engine import CvrpEngine, PackedPolicy
+from .nn_layout import DecoderParams, EncoderParams
+
+SHIPPED_INFO = [True, True, True, False, True, True, False, False, False, False, False, False, False]
+
+
+def get_random_problems(batch_size, problem_size):
+    """CVRP/CVRPEnv.py:30-51 (demand scaler 30 / 40 for 20 / 50 customers, 500 otherwise)."""
+    depot_xy = torch.rand(size=(batch_size, 1, 2))
+    node_xy = torch.rand(size=(batch_size, problem_size, 2))
+    scaler = {20: 30, 50: 40}.get(problem_size, 500)
+    node_demand = torch.randint(1, 200, size=(batch_size, problem_size)) / float(scaler)
+    return depot_xy, node_xy, node_demand
+
+
+def read_cvrp_instances_from_file(file_path):
+    """"depot .|. nodes .|. demands .|. capacity" per line (CVRP/CVRPEnv.py:83-111)."""
+    depot, nodes, demands = [], [], []
+    with open(file_path, "r", encoding="utf8") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            part = line.strip().split(" .|. ")
+            depot.append([float(x) for x in part[0].strip().split(",")])
+            nodes.append([[float(x) for x in tok.split(",")] for tok in part[1].strip().split(" ")])
+            cap = int(part[3])
+            demands.append((torch.Tensor([int(x) for x in part[2].strip().split(" ")]) / cap).tolist())
+    return torch.Tensor(depot), torch.Tensor(nodes), torch.Tensor(demands)
+
+
+@dataclass
+class Reset_State:
+    problems: torch.Tensor
+
+
+class Step_State:
+    """CVRP/CVRPEnv.py:170-180, backed by the device engine."""
+
+    def __init__(self, engine: CvrpEngine):
+        self.engine = engine
+
+    @property
+    def data(self) -> torch.Tensor:
+        e = self.engine
+        if e.t == 0:
+            return torch.cat((e.xy, e.demand[:, :, None]), 2).repeat_interleave(e.rpi, 0)
+        return e.data()
+
+    @property
+    def avg_unselect_distence(self):
+        return self.engine.state["avg"]
+
+    @property
+    def std_dev_unselect_distence(self):
+        return self.engine.state["sd"]
+
+    @property
+    def capacity(self):
+        return self.engine.state["capacity"]
+
+    @property
+    def ninf_mask(self) -> torch.Tensor:
+        """0 / -inf feasibility mask [R,N+1] (CVRP/CVRPEnv.py:633-637), derived on access."""
+        e = self.engine
+        dem = e.demand.repeat_interleave(e.rpi, 0)
+        mask = torch.zeros_like(dem)
+        mask[(e.state["capacity"][:, None] + 0.000001) < dem] = float("-inf")
+        return mask
+
+    @property
+    def selected_flag(self) -> torch.Tensor:
+        e = self.engine
+        return e.state["flags"][:, :e.t].to(torch.int64)
+
+
+class CVRPEnv:
+    def __init__(self, **env_params):
+        self.env_params = env_params
+        self.problem_size = None
+        self.mode = env_params["mode"]
+        if self.mode == "test":
+            if env_params["test_mode"] == "pomo_test":
+                self.pomo_size = env_params["aug_size"]
+            elif env_params["test_mode"] == "aug_test":
+                raise NotImplementedError("aug_test (coordinate augmentation) is not part of this build yet")
+        else:
+            self.pomo_size = env_params["pomo_size"]
+        info = list(env_params.get("append_information", SHIPPED_INFO))
+        if info[:len(SHIPPED_INFO)] != SHIPPED_INFO:
+            raise NotImplementedError("only the shipped feature set (append_information 0,1,2,4,5) is implemented")
+        self.append_information = info
+        self.device = torch.device(env_params.get("device", "cuda"))
+        self.knn = env_params.get("knn", 15)
+        self.depot_knn = env_params.get("depot_knn", 15)
+        self.batch_size = None
+        self.problems = None
+        self.step_state = None
+        self.engine: Optional[CvrpEngine] = None
+        self.beam_size = 1
+        self.start_idx = 0
+        self.step_size = None
+        self.dis_matrix = None
+        self.solution = None
+        self.solution_flag = None
+        self.solution_len = None
+        self.selected_count = None
+
+    def load_data(self, test_episode, problem_size):
+        self.raw_depot_node_xy, self.raw_node_xy, self.raw_node_demand = \
+            read_cvrp_instances_from_file(self.env_params["data_path"])
+
+    def load_problems(self, episode, batch_size, problem_size):
+        """CVRP/CVRPEnv.py:222-264."""
+        self.episode = episode
+        self.batch_size = batch_size
+        self.problem_size = problem_size
+        if self.mode == "train":
+            depot_xy, node_xy, node_demand = get_random_problems(batch_size, problem_size)
+            self.depot_node_xy = torch.cat((depot_xy, node_xy), dim=1)
+        else:
+            depot_xy = self.raw_depot_node_xy[episode:episode + batch_size]
+            node_xy = self.raw_node_xy[episode:episode + batch_size]
+            node_demand = self.raw_node_demand[episode:episode + batch_size]
+            self.depot_node_xy = torch.cat((depot_xy[:, None, :], node_xy), dim=1)
+        self.depot_node_demand = torch.cat((torch.zeros(size=(batch_size, 1)), node_demand), dim=1)
+        self.problems = torch.cat((self.depot_node_xy, self.depot_node_demand[:, :, None]), dim=2)
+        self.solution = None
+        self.solution_len = None
+
+    def reset(self, mode):
+        if mode not in ("test", "valid"):
+            raise NotImplementedError("the training reset (augmented coordinates) is not part of this build yet")
+        self.mode = mode
+        self.selected_count = 0
+        nb = self.batch_size if mode == "test" else self.step_size
+        sl = slice(self.start_idx, self.start_idx + nb)
+        xy = self.depot_node_xy[sl].to(self.device, torch.float32).contiguous()
+        dem = self.depot_node_demand[sl].to(self.device, torch.float32).contiguous()
+        self.engine = CvrpEngine(xy, dem, self.pomo_size * self.beam_size, self.knn, self.depot_knn)
+        self.engine.reset()
+        self.step_state = Step_State(self.engine)
+        self._permuted_at = -1
+        return Reset_State(self.problems), None, False
+
+    def pre_step(self):
+        return self.step_state, None, False
+
+    @property
+    def selected_node_list(self) -> torch.Tensor:
+        e = self.engine
+        return e.state["nodes"][:, :e.t].to(torch.int64)
+
+    @selected_node_list.setter
+    def selected_node_list(self, value):
+        pass        # see TSPEnv.selected_node_list
+
+    def perm_attr(self, attr_name, prev_k):
+        """CVRP/CVRPEnv.py:536-581; the compact state is re-indexed once per beam step."""
+        e = self.engine
+        if self._permuted_at == e.t or self.beam_size == 1:     # beam 1: the back-pointer is always 0
+            return
+        e.permute(prev_k.to(torch.int32).contiguous(), self.beam_size)
+        self._permuted_at = e.t
+
+    def step(self, selected):
+        """``selected`` holds action ids; like the reference (CVRP/CVRPEnv.py:619) the caller's tensor
+        is rewritten to node ids for via-depot moves."""
+        e = self.engine
+        act = selected.to(device=self.device, dtype=torch.int32).contiguous()
+        via = selected > self.problem_size
+        selected[via] = selected[via] - (self.problem_size + 1)
+        self.selected_count += 1
+        e.step(act)
+        done = self.selected_count == self.problem_size
+        reward = e.route_length().clone() if done else (None, None)
+        return self.step_state, reward, done
+
+    def cal_length(self, problems=None, order_node=None, order_flag=None):
+        return self.engine.route_length().clone()
+
+
+class CVRPModel(nn.Module):
+    def __init__(self, **model_params):
+        super().__init__()
+        self.model_params = model_params
+        self.mode = model_params["mode"]
+        if (model_params["embedding_dim"], model_params["head_num"], model_params["qkv_dim"],
+                model_params["ff_hidden_dim"], model_params["decoder_layer_num"]) != (128, 8, 16, 512, 3):
+            raise NotImplementedError("kernels are specialised for embedding 128, 8 heads x 16, FF 512, 3 decoder layers")
+        self.encoder = EncoderParams(9)
+        self.decoder = DecoderParams("CVRP")
+        self._packed = None
+        self._packed_key = None
+
+    def pre_forward(self, dis_matrix, batch_size):
+        self.dis_matrix = dis_matrix
+        self.batch_size = batch_size
+
+    def packed(self, device) -> PackedPolicy:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or key != self._packed_key:
+            self._packed = PackedPolicy(self.state_dict(), PROBLEM_CVRP, device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, state, selected_node_list, solution, solution_flag, knn, current_step, depot_knn_nums,
+                selected_flag=None):
+        if self.mode == "train":
+            raise NotImplementedError("the teacher-forced training step is not part of this build yet")
+        eng: CvrpEngine = state.engine
+        if knn + depot_knn_nums + 2 > 32:
+            raise NotImplementedError("more than 32 tokens per row (knn + depot_knn + 2) is not supported yet")
+        eng.set_knn(knn, depot_knn_nums)
+        eng.ensure_neighbourhood()
+        eng.forward(self.packed(eng.device))
+        return None, eng.dense_probs(), 1

@@ -69,7 +69,7 @@ class TspEngine:
         self.device = dev
         R, N = self.R, self.N
         self.W = (N + 63) // 64
-        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]
+        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]   # 2nd copy: beam permutation target
         self.cur = 0
         self.idx = torch.empty(R, knn, dtype=torch.int32, device=dev)
         self.tile = torch.zeros(R, (knn + 1) * TILE_STRIDE, dtype=torch.float32, device=dev)
@@ -228,7 +228,7 @@ class CvrpEngine:
         R = self.R
         self.W = (self.M + 63) // 64
         self.ntok_max = knn + depot_knn + 2
-        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]
+        self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]   # 2nd copy: beam permutation target
         self.cur = 0
         self.idx_last = torch.empty(R, knn, dtype=torch.int32, device=dev)
         self.idx_dep = torch.empty(R, depot_knn, dtype=torch.int32, device=dev)

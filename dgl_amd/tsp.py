@@ -1,0 +1,198 @@
+"""TSP host side with the reference's interface: TSPEnv (TSP/TSPEnv.py), TSPModel
+(TSP/TSPModel.py).  Same constructor dictionaries, method names, argument meaning and
+checkpoint keys; the bodies call the HIP kernels through the C ABI (dgl_amd.engine).
+
+Differences a caller can observe:
+  * state lives on the GPU in compact form; ``step_state.data`` ([R,N,7]) is materialised on
+    access (dgl_tsp_state_data) instead of being updated in place;
+  * ``env.dis_matrix`` is never built (distances are recomputed from coordinates with the
+    arithmetic of torch.cdist's matrix-product path), ``model.pre_forward`` accepts ``None``;
+  * only the shipped feature switches (append_information 0,1,2,4,5) are implemented;
+  * index tensors are int64 at this boundary (as in the reference) and int32 on the device.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import PROBLEM_TSP
+from .engine import PackedPolicy, TspEngine
+from .nn_layout import DecoderParams, EncoderParams
+
+SHIPPED_INFO = [True, True, True, False, True, True, False, False, False, False, False]
+
+
+@dataclass
+class Reset_State:
+    problems: torch.Tensor
+
+
+class Step_State:
+    """TSP/TSPEnv.py:39-43, backed by the device engine."""
+
+    def __init__(self, engine: TspEngine):
+        self.engine = engine
+
+    @property
+    def data(self) -> torch.Tensor:
+        e = self.engine
+        if e.t == 0:
+            return e.xy.repeat_interleave(e.rpi, 0)
+        return e.data()
+
+    @property
+    def avg_unselect_distence(self) -> torch.Tensor:
+        return self.engine.state["avg"]
+
+    @property
+    def std_dev_unselect_distence(self) -> torch.Tensor:
+        return self.engine.state["sd"]
+
+
+def get_random_problems(batch_size, problem_size):
+    return torch.rand(size=(batch_size, problem_size, 2))       # TSP/TSPEnv.py:29-32
+
+
+class TSPEnv:
+    def __init__(self, **env_params):
+        self.env_params = env_params
+        self.problem_size = None
+        self.data_path = env_params.get("data_path", "")
+        self.mode = env_params["mode"]
+        if self.mode == "test":
+            self.baseline_path = env_params.get("baseline_path", "")
+            if env_params["test_mode"] == "pomo_test":
+                self.pomo_size = env_params["aug_size"]
+            elif env_params["test_mode"] == "aug_test":
+                raise NotImplementedError("aug_test (coordinate augmentation) is not part of this build yet")
+        else:
+            self.pomo_size = env_params["pomo_size"]
+        info = list(env_params.get("append_information", SHIPPED_INFO))
+        if info[:len(SHIPPED_INFO)] != SHIPPED_INFO:
+            raise NotImplementedError("only the shipped feature set (append_information 0,1,2,4,5) is implemented")
+        self.append_information = info
+        self.device = torch.device(env_params.get("device", "cuda"))
+        self.knn = env_params.get("knn", 30)       # neighbourhood built inside step(); the model may override it
+        self.batch_size = None
+        self.problems = None
+        self.raw_data_nodes = []
+        self.baseline_len = []
+        self.selected_count = None
+        self.step_state = None
+        self.engine: Optional[TspEngine] = None
+        self.beam_size = 1
+        self.start_idx = 0
+        self.step_size = None
+        self.dis_matrix = None
+        self.solution = None
+        self.solution_len = None
+
+    # ---- data ---------------------------------------------------------------------
+    def load_data(self, test_episode, problem_size):
+        """Instance text file "x,y x,y ..." and optional baseline-length file (TSP/TSPEnv.py:82-106)."""
+        with open(self.data_path, "r") as f:
+            pts = [[float(v) for v in tok.split(",")] for tok in f.read().split()]
+        self.raw_data_nodes = torch.tensor(pts, dtype=torch.float32).view(test_episode, problem_size, 2)
+        self.baseline_len = []
+        if self.baseline_path != "":
+            with open(self.baseline_path, "r") as f:
+                self.baseline_len = torch.tensor([float(line.split()[1]) for line in f])
+
+    def load_problems(self, episode, batch_size, problem_size, beam_size):
+        self.episode = episode
+        self.batch_size = batch_size
+        self.problem_size = problem_size
+        if self.mode == "train":
+            self.problems = get_random_problems(batch_size, problem_size)
+        else:
+            self.problems = self.raw_data_nodes[episode:episode + batch_size]
+        self.beam_size = beam_size
+        self.solution = None
+        self.solution_len = None
+
+    # ---- episode --------------------------------------------------------------------
+    def reset(self, mode):
+        if mode not in ("test", "valid"):
+            raise NotImplementedError("the training reset (augmented coordinates) is not part of this build yet")
+        self.mode = mode
+        self.selected_count = 0
+        nb = self.batch_size if mode == "test" else self.step_size
+        xy = self.problems[self.start_idx:self.start_idx + nb].to(self.device, torch.float32).contiguous()
+        self.engine = TspEngine(xy, self.pomo_size * self.beam_size, self.knn)
+        self.engine.reset()
+        self.step_state = Step_State(self.engine)
+        self._permuted_at = -1
+        return Reset_State(self.problems), None, False
+
+    def pre_step(self):
+        return self.step_state, None, False
+
+    @property
+    def selected_node_list(self) -> torch.Tensor:
+        e = self.engine
+        return e.state["tour"][:, :e.t].to(torch.int64)
+
+    @selected_node_list.setter
+    def selected_node_list(self, value):
+        # Beamsearch.advance returns the re-indexed list and the tester assigns it back
+        # (TSP/TSPTester.py:174); the device copy was already permuted by perm_attr.
+        pass
+
+    def perm_attr(self, attr_name, prev_k):
+        """TSP/TSPEnv.py:278-308.  The whole compact state is re-indexed once per beam step, by the
+        first attribute asked for."""
+        e = self.engine
+        if self._permuted_at == e.t or self.beam_size == 1:     # beam 1: the back-pointer is always 0
+            return
+        e.permute(prev_k.to(torch.int32).contiguous(), self.beam_size)
+        self._permuted_at = e.t
+
+    def step(self, selected):
+        e = self.engine
+        self.selected_count += 1
+        e.step(selected.to(device=self.device, dtype=torch.int32).contiguous())
+        done = self.selected_count == self.problem_size
+        reward = self._get_travel_distance() if done else (None, None)
+        return self.step_state, reward, done
+
+    def _get_travel_distance(self, instances=None):
+        return self.engine.tour_length().clone()
+
+
+class TSPModel(nn.Module):
+    """Parameter container with the reference's state_dict keys; forward runs the HIP kernels."""
+
+    def __init__(self, **model_params):
+        super().__init__()
+        self.model_params = model_params
+        self.mode = model_params["mode"]
+        if (model_params["embedding_dim"], model_params["head_num"], model_params["qkv_dim"],
+                model_params["ff_hidden_dim"], model_params["decoder_layer_num"]) != (128, 8, 16, 512, 3):
+            raise NotImplementedError("kernels are specialised for embedding 128, 8 heads x 16, FF 512, 3 decoder layers")
+        self.encoder = EncoderParams(7)
+        self.decoder = DecoderParams("TSP")
+        self._packed = None
+        self._packed_key = None
+
+    def pre_forward(self, dis_matrix, batch_size):
+        self.dis_matrix = dis_matrix
+        self.batch_size = batch_size
+
+    def packed(self, device) -> PackedPolicy:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or key != self._packed_key:
+            self._packed = PackedPolicy(self.state_dict(), PROBLEM_TSP, device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, state, selected_node_list, solution, knn, current_step):
+        if self.mode == "train":
+            raise NotImplementedError("the teacher-forced training step is not part of this build yet")
+        eng: TspEngine = state.engine
+        eng.set_knn(knn)
+        eng.ensure_neighbourhood()
+        eng.forward(self.packed(eng.device))
+        return None, eng.dense_probs(), 1

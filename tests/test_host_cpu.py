@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: checkpoint layout, sharding, statistics all-reduce (gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN
+
+
+def test_state_dict_layout_matches_reference_checkpoints():
+    from dgl_amd.cvrp import CVRPModel
+    from dgl_amd.tsp import TSPModel
+    from dgl_amd.weights import load_checkpoint, random_state_dict, state_dict_shapes
+    mp_ = dict(mode="test", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3, qkv_dim=16, head_num=8,
+               ff_hidden_dim=512)
+    for cls, pb, n in ((TSPModel, "TSP", 46), (CVRPModel, "CVRP", 48)):
+        m = cls(**mp_)
+        sd = m.state_dict()
+        assert len(sd) == n
+        assert {k: tuple(v.shape) for k, v in sd.items()} == state_dict_shapes(pb)
+        ck = load_checkpoint(os.path.join(GOLDEN, f"ckpt_{pb.lower()}_nn.pt"))      # written by the reference's classes
+        assert set(ck) == set(sd)
+        m.load_state_dict(ck)
+        assert set(random_state_dict(pb, 1)) == set(sd)
+        assert sum(v.numel() for v in sd.values()) == (840193 if pb == "TSP" else 856961)
+
+
+def test_unsupported_configurations_fail_loudly():
+    from dgl_amd.tsp import TSPEnv, TSPModel
+    with pytest.raises(NotImplementedError):
+        TSPModel(mode="test", embedding_dim=256, head_num=8, qkv_dim=16, ff_hidden_dim=512, decoder_layer_num=3)
+    info = [True] * 11
+    with pytest.raises(NotImplementedError):
+        TSPEnv(mode="test", test_mode="pomo_test", aug_size=1, append_information=info, data_path="", device="cpu")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dgl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DglError):
+        _lib.load()
+
+
+def test_shard_range_covers_everything():
+    from dgl_amd.distributed import shard_range
+    for total in (0, 1, 7, 8, 20, 200, 2000):
+        for ws in (1, 2, 3, 8):
+            got = []
+            for r in range(ws):
+                lo, hi = shard_range(total, r, ws)
+                assert 0 <= lo <= hi <= total
+                got += list(range(lo, hi))
+            assert got == list(range(total))
+
+
+def _worker(rank, ws, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from dgl_amd.distributed import reduce_stats, shard_range, world
+    assert world() == (rank, ws)
+    lengths = np.arange(101, dtype=np.float64) * 0.25 + 3.0          # per-instance "tour lengths"
+    base = lengths * 0.9
+    lo, hi = shard_range(len(lengths), rank, ws)
+    s, g, c = reduce_stats(float(lengths[lo:hi].sum()), float(((lengths[lo:hi] - base[lo:hi]) / base[lo:hi]).sum()),
+                           float(hi - lo))
+    out[rank] = (s, g, c)
+    dist.destroy_process_group()
+
+
+def test_stats_allreduce_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    lengths = np.arange(101, dtype=np.float64) * 0.25 + 3.0
+    for r in (0, 1):
+        s, g, c = out[r]
+        assert c == 101 and abs(s - lengths.sum()) < 1e-9 and abs(g - 101 * (1 / 0.9 - 1)) < 1e-9
+
+
+def test_cvrp_instance_file_parser(tmp_path):
+    from dgl_amd.cvrp import read_cvrp_instances_from_file
+    p = tmp_path / "cvrp.txt"
+    p.write_text("0.5,0.5 .|. 0.1,0.2 0.3,0.4 0.9,0.8 .|. 10 20 5 .|. 50\n0.1,0.9 .|. 0.2,0.2 0.4,0.4 0.6,0.6 .|. 1 2 3 .|. 10\n")
+    depot, nodes, dem = read_cvrp_instances_from_file(str(p))
+    assert depot.shape == (2, 2) and nodes.shape == (2, 3, 2) and dem.shape == (2, 3)
+    np.testing.assert_allclose(dem.numpy(), [[0.2, 0.4, 0.1], [0.1, 0.2, 0.3]])
