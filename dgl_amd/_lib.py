@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdgl_amd.so")
+LIB_PATH = os.environ.get("DGL_AMD_LIB", os.path.join(_HERE, "lib", "libdgl_amd.so"))
 
 TILE_STRIDE = 12
 MAX_TOKENS = 32

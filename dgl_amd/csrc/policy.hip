@@ -20,6 +20,9 @@
 // softmax probabilities stay in the accumulator layout that the P.V MFMA consumes as its
 // B operand: the attention needs no LDS traffic and no cross-lane shuffles beyond one
 // exchange between the two half-waves.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,39 +34,43 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define EMB_IN DGL_TILE_STRIDE        // padded input features
 
 // ---- packed weight layout (float offsets) ---------------------------------------
-#define PK_LIN128 (D_MODEL * D_MODEL)               // 16384: one packed 128x128 matrix
+// Small vectors first, then one weight STREAM per wave: the 1 KB fragments (64 lanes x 16 B) a
+// wave consumes, in exactly the order it consumes them, so that a wave's weight traffic is one
+// linear read which a register ring prefetches PF fragments ahead across GEMM boundaries.
+//   per block : 48 fragments q,k,v interleaved by K-chunk; 16 combine; 4 x (16 W1 + 16 W2)
+//   stream    : block 0 | anchor embedding(s) 2 x 16 (TSP repeats its single one) | blocks 1..3
 #define PK_EMB_W 0
 #define PK_EMB_B (PK_EMB_W + D_MODEL * EMB_IN)
-#define PK_BLOCK0 (PK_EMB_B + D_MODEL)
-#define PKB_WQ 0
-#define PKB_WK (PKB_WQ + PK_LIN128)
-#define PKB_WV (PKB_WK + PK_LIN128)
-#define PKB_WC (PKB_WV + PK_LIN128)
-#define PKB_BC (PKB_WC + PK_LIN128)
-#define PKB_W1 (PKB_BC + D_MODEL)
-#define PKB_B1 (PKB_W1 + FF_DIM * D_MODEL)
-#define PKB_W2 (PKB_B1 + FF_DIM)
-#define PKB_B2 (PKB_W2 + FF_DIM * D_MODEL)
-#define PK_BLOCK_SIZE (PKB_B2 + D_MODEL)
-#define PK_ANCHOR0 (PK_BLOCK0 + 4 * PK_BLOCK_SIZE)
-#define PK_ANCHOR_SIZE (PK_LIN128 + D_MODEL)
-#define PK_FINAL_W (PK_ANCHOR0 + 2 * PK_ANCHOR_SIZE)
+#define PK_VEC0 (PK_EMB_B + D_MODEL)               // per block: bc[128] b1[512] b2[128]
+#define PKV_BC 0
+#define PKV_B1 (PKV_BC + D_MODEL)
+#define PKV_B2 (PKV_B1 + FF_DIM)
+#define PKV_SIZE (PKV_B2 + D_MODEL)
+#define PK_ANCHOR_B (PK_VEC0 + 4 * PKV_SIZE)       // [2][128]
+#define PK_FINAL_W (PK_ANCHOR_B + 2 * D_MODEL)
 #define PK_FINAL_B (PK_FINAL_W + D_MODEL)
-#define PK_TOTAL (PK_FINAL_B + 4)
+#define PK_STREAM0 (PK_FINAL_B + 4)
+#define FRAG 256                                    // floats per fragment
+#define BLK_FRAGS 192                               // fragments per wave per block
+#define ANCHOR_FRAGS 32
+#define WAVE_FRAGS (4 * BLK_FRAGS + ANCHOR_FRAGS)   // 800
+#define PF 8                                        // prefetch depth (fragments in flight per wave)
+#define PK_TOTAL (PK_STREAM0 + (4 * WAVE_FRAGS + PF) * FRAG)
 
 extern "C" int64_t dgl_policy_packed_floats(int32_t) { return PK_TOTAL; }
 
-// dst[((ot*C + c)*64 + lane)*4 + e] = W[32*ot + (lane&31)][8c + 4(lane>>5) + e],  C = IN/8
-__global__ void pack_linear_kernel(const float *__restrict__ W, int OUT, int IN, float *__restrict__ dst) {
-    const int total = OUT * IN;
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
-        const int e = o & 3, lane = (o >> 2) & 63, blk = o >> 8;
-        const int C = IN / 8, c = blk % C, ot = blk / C;
-        dst[o] = W[(size_t)(32 * ot + (lane & 31)) * IN + 8 * c + 4 * (lane >> 5) + e];
+// Fragment j (j = 0..nc-1) of out tile `ot`, K-chunks c0..c0+nc-1 of W[OUT][IN]:
+//   dst[(j*stride)*256 + lane*4 + e] = W[32*ot + (lane&31)][8(c0+j) + 4(lane>>5) + e]
+__global__ void pack_tile_kernel(const float *__restrict__ W, int IN, int ot, int c0, int nc, float *__restrict__ dst,
+                                 int stride) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < nc * FRAG; o += gridDim.x * blockDim.x) {
+        const int e = o & 3, lane = (o >> 2) & 63, j = o >> 8;
+        dst[(size_t)j * stride * FRAG + lane * 4 + e] =
+            W[(size_t)(32 * ot + (lane & 31)) * IN + 8 * (c0 + j) + 4 * (lane >> 5) + e];
     }
 }
 __global__ void pack_copy_kernel(const float *__restrict__ src, int n, float *__restrict__ dst) {
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) dst[o] = src[o];
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) dst[o] = src ? src[o] : 0.0f;
 }
 // encoder.embedding [128][F] -> [128][EMB_IN], zero padded
 __global__ void pack_emb_kernel(const float *__restrict__ W, int F, float *__restrict__ dst) {
@@ -79,8 +86,14 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
     hipStream_t s = (hipStream_t)stream;
     const int F = w->problem == DGL_PROBLEM_TSP ? 7 : 9;
     DGL_CHECK_ARG(w->emb_w && w->emb_b && w->final_w && w->final_b && w->anchor_w[0] && w->anchor_b[0], "NULL weight");
-    auto lin = [&](const float *W, int OUT, int IN, int off) {
-        hipLaunchKernelGGL(pack_linear_kernel, dim3(64), dim3(256), 0, s, W, OUT, IN, packed + off);
+    for (int b = 0; b < 4; ++b) {
+        const dgl_block_weights_t &k = w->block[b];
+        DGL_CHECK_ARG(k.wq && k.wk && k.wv && k.wc && k.bc && k.w1 && k.b1 && k.w2 && k.b2, "NULL weight in block %d", b);
+    }
+    if (w->problem == DGL_PROBLEM_CVRP) DGL_CHECK_ARG(w->anchor_w[1] && w->anchor_b[1], "NULL second anchor embedding");
+    auto tile = [&](const float *W, int IN, int ot, int c0, int nc, size_t frag, int stride) {
+        hipLaunchKernelGGL(pack_tile_kernel, dim3(4), dim3(256), 0, s, W, IN, ot, c0, nc,
+                           packed + PK_STREAM0 + frag * FRAG, stride);
     };
     auto vec = [&](const float *v, int n, int off) {
         hipLaunchKernelGGL(pack_copy_kernel, dim3(1), dim3(256), 0, s, v, n, packed + off);
@@ -89,26 +102,31 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
     vec(w->emb_b, D_MODEL, PK_EMB_B);
     for (int b = 0; b < 4; ++b) {
         const dgl_block_weights_t &k = w->block[b];
-        DGL_CHECK_ARG(k.wq && k.wk && k.wv && k.wc && k.bc && k.w1 && k.b1 && k.w2 && k.b2, "NULL weight in block %d", b);
-        const int o = PK_BLOCK0 + b * PK_BLOCK_SIZE;
-        lin(k.wq, D_MODEL, D_MODEL, o + PKB_WQ);
-        lin(k.wk, D_MODEL, D_MODEL, o + PKB_WK);
-        lin(k.wv, D_MODEL, D_MODEL, o + PKB_WV);
-        lin(k.wc, D_MODEL, D_MODEL, o + PKB_WC);
-        vec(k.bc, D_MODEL, o + PKB_BC);
-        lin(k.w1, FF_DIM, D_MODEL, o + PKB_W1);
-        vec(k.b1, FF_DIM, o + PKB_B1);
-        lin(k.w2, D_MODEL, FF_DIM, o + PKB_W2);
-        vec(k.b2, D_MODEL, o + PKB_B2);
+        vec(k.bc, D_MODEL, PK_VEC0 + b * PKV_SIZE + PKV_BC);
+        vec(k.b1, FF_DIM, PK_VEC0 + b * PKV_SIZE + PKV_B1);
+        vec(k.b2, D_MODEL, PK_VEC0 + b * PKV_SIZE + PKV_B2);
     }
-    for (int a = 0; a < 2; ++a) {
-        const int src = (w->problem == DGL_PROBLEM_CVRP) ? a : 0;
-        DGL_CHECK_ARG(w->anchor_w[src] && w->anchor_b[src], "NULL anchor embedding %d", src);
-        lin(w->anchor_w[src], D_MODEL, D_MODEL, PK_ANCHOR0 + a * PK_ANCHOR_SIZE);
-        vec(w->anchor_b[src], D_MODEL, PK_ANCHOR0 + a * PK_ANCHOR_SIZE + PK_LIN128);
-    }
+    for (int a = 0; a < 2; ++a) vec(w->anchor_b[w->problem == DGL_PROBLEM_CVRP ? a : 0], D_MODEL, PK_ANCHOR_B + a * D_MODEL);
     vec(w->final_w, D_MODEL, PK_FINAL_W);
     vec(w->final_b, 1, PK_FINAL_B);
+    for (int wv = 0; wv < 4; ++wv) {
+        for (int b = 0; b < 4; ++b) {
+            const dgl_block_weights_t &k = w->block[b];
+            size_t f = (size_t)wv * WAVE_FRAGS + (size_t)b * BLK_FRAGS + (b > 0 ? ANCHOR_FRAGS : 0);
+            tile(k.wq, D_MODEL, wv, 0, 16, f + 0, 3);
+            tile(k.wk, D_MODEL, wv, 0, 16, f + 1, 3);
+            tile(k.wv, D_MODEL, wv, 0, 16, f + 2, 3);
+            tile(k.wc, D_MODEL, wv, 0, 16, f + 48, 1);
+            for (int hc = 0; hc < 4; ++hc) {
+                tile(k.w1, D_MODEL, 4 * hc + wv, 0, 16, f + 64 + 32 * hc, 1);
+                tile(k.w2, FF_DIM, wv, 16 * hc, 16, f + 64 + 32 * hc + 16, 1);
+            }
+        }
+        for (int a = 0; a < 2; ++a)
+            tile(w->anchor_w[w->problem == DGL_PROBLEM_CVRP ? a : 0], D_MODEL, wv, 0, 16,
+                 (size_t)wv * WAVE_FRAGS + BLK_FRAGS + 16 * a, 1);
+    }
+    vec(nullptr, PF * FRAG, PK_STREAM0 + 4 * WAVE_FRAGS * FRAG);      // zero tail the prefetch ring may read
     DGL_CHECK_LAUNCH("dgl_policy_pack");
     return DGL_OK;
 }
@@ -116,21 +134,67 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
 // ---- device building blocks ----------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// acc[rr] += W(out tile) * X[rr]^T   (transposed product: lane = token, registers = features)
-//   wp: packed weights of this out tile, already offset by lane (float4 units), chunk stride 64
-//   xp: LDS pointer X[row 0][token q][4h]; xrow = floats between rows
-template <int ROWS, int NCHUNK>
-__device__ __forceinline__ void gemm_t(const f32x4 *__restrict__ wp, const float *xp, int xrow, f32x16 (&acc)[ROWS]) {
+// Register ring holding the next PF weight fragments of this wave's stream.  take<SLOT>() returns
+// the oldest fragment and immediately re-issues the slot's load PF fragments ahead, so weight
+// loads stay in flight across MFMAs, epilogues and barriers.
+struct WeightRing {
+    f32x4 r[PF];
+    const f32x4 *next;      // this lane's 16 bytes of the next fragment to request
+    __device__ __forceinline__ void fill(const f32x4 *p) {
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        const f32x4 w = wp[c * 64];
-#pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(xp + rr * xrow + 8 * c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[rr] = MFMA(w[e], x[e], acc[rr]);
-        }
+        for (int i = 0; i < PF; ++i) r[i] = p[i * 64];
+        next = p + PF * 64;
     }
+    template <int SLOT>
+    __device__ __forceinline__ f32x4 take() {
+        const f32x4 v = r[SLOT];
+        r[SLOT] = *next;
+#ifndef EXP_SAMEFRAG
+        next += 64;
+#endif
+        return v;
+    }
+};
+
+template <int C, int N>
+struct Unroll {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, C>{});
+        Unroll<C + 1, N>::run(f);
+    }
+};
+template <int N>
+struct Unroll<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+// acc[rr] += W(out tile) * X[rr]^T over 16 K-chunks (transposed product: lane = token,
+// registers = features).  xp: LDS pointer X[row 0][token q][4h]; xrow = floats between rows.
+template <int ROWS>
+__device__ __forceinline__ void gemm_t(WeightRing &ring, const float *xp, int xrow, f32x16 (&acc)[ROWS]) {
+    // X operands are read from LDS one K-chunk ahead of the MFMAs that consume them, so the
+    // ~100+ cycle LDS latency hides behind eight 64-cycle MFMAs instead of stalling each chunk.
+    f32x4 xn[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) xn[rr] = *reinterpret_cast<const f32x4 *>(xp + rr * xrow);
+    Unroll<0, 16>::run([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const f32x4 w = ring.template take<c % PF>();
+        f32x4 x[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) x[rr] = xn[rr];
+        if constexpr (c + 1 < 16) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) xn[rr] = *reinterpret_cast<const f32x4 *>(xp + rr * xrow + 8 * (c + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads ahead of this chunk's MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) acc[rr] = MFMA(w[e], x[rr][e], acc[rr]);
+    });
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -150,6 +214,9 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
     const int row0 = blockIdx.x * ROWS;
     const int n = io.n;
     constexpr int XROW = 32 * LDX;
+
+    WeightRing ring;
+    ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM0 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
 
     // ---- embedding: X[token][c] = b[c] + sum_f tile[token][f] * We[c][f] ----------
     {
@@ -186,24 +253,23 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
     const int anchor0 = io.k_last, anchor1 = n - 1;    // TSP: k_last == n-1
 
     for (int layer = 0; layer < 4; ++layer) {
-        const float *PB = P + PK_BLOCK0 + layer * PK_BLOCK_SIZE;
+        const float *PV = P + PK_VEC0 + layer * PKV_SIZE;
 
         if (layer == 1) {
             // decoder entry: re-embed the anchor token(s) (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-446)
-            const int na = (io.problem == DGL_PROBLEM_CVRP) ? 2 : 1;
-            for (int a = 0; a < na; ++a) {
-                const float *PA = P + PK_ANCHOR0 + a * PK_ANCHOR_SIZE;
+            // (the stream always carries two embeddings; TSP's second equals its first and is discarded)
+            for (int a = 0; a < 2; ++a) {
                 f32x16 acc[ROWS];
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
-                gemm_t<ROWS, 16>(reinterpret_cast<const f32x4 *>(PA + w * 16 * 256) + lane, xa_lane, XROW, acc);
+                gemm_t<ROWS>(ring, xa_lane, XROW, acc);
                 __syncthreads();                       // every wave has finished reading XA
                 const int tok = (a == 0) ? anchor0 : anchor1;
-                if (q == tok) {
+                if (q == tok && (a == 0 || io.problem == DGL_PROBLEM_CVRP)) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int f = 32 * w + 8 * g + 4 * h;
-                        const f32x4 bb = *reinterpret_cast<const f32x4 *>(PA + PK_LIN128 + f);
+                        const f32x4 bb = *reinterpret_cast<const f32x4 *>(P + PK_ANCHOR_B + a * D_MODEL + f);
 #pragma unroll
                         for (int rr = 0; rr < ROWS; ++rr) {
                             f32x4 o;
@@ -222,23 +288,33 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) { aq[rr] = zero16(); ak[rr] = zero16(); av[rr] = zero16(); }
         {
-            const f32x4 *wq = reinterpret_cast<const f32x4 *>(PB + PKB_WQ + w * 16 * 256) + lane;
-            const f32x4 *wk = reinterpret_cast<const f32x4 *>(PB + PKB_WK + w * 16 * 256) + lane;
-            const f32x4 *wv = reinterpret_cast<const f32x4 *>(PB + PKB_WV + w * 16 * 256) + lane;
+            f32x4 xn[ROWS];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const f32x4 fq = wq[c * 64], fk = wk[c * 64], fv = wv[c * 64];
+            for (int rr = 0; rr < ROWS; ++rr) xn[rr] = *reinterpret_cast<const f32x4 *>(xa_lane + rr * XROW);
+            Unroll<0, 16>::run([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const f32x4 fq = ring.template take<(3 * c) % PF>();
+                const f32x4 fk = ring.template take<(3 * c + 1) % PF>();
+                const f32x4 fv = ring.template take<(3 * c + 2) % PF>();
+                f32x4 x[ROWS];
 #pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) {
-                    const f32x4 x = *reinterpret_cast<const f32x4 *>(xa_lane + rr * XROW + 8 * c);
+                for (int rr = 0; rr < ROWS; ++rr) x[rr] = xn[rr];
+                if constexpr (c + 1 < 16) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        aq[rr] = MFMA(fq[e], x[e], aq[rr]);
-                        ak[rr] = MFMA(fk[e], x[e], ak[rr]);
-                        av[rr] = MFMA(x[e], fv[e], av[rr]);
+                    for (int rr = 0; rr < ROWS; ++rr)
+                        xn[rr] = *reinterpret_cast<const f32x4 *>(xa_lane + rr * XROW + 8 * (c + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+                        aq[rr] = MFMA(fq[e], x[rr][e], aq[rr]);
+                        ak[rr] = MFMA(fk[e], x[rr][e], ak[rr]);
+                        av[rr] = MFMA(x[rr][e], fv[e], av[rr]);
                     }
                 }
-            }
+            });
         }
 
         // ---- attention, both local heads, straight from the accumulators -----------
@@ -252,23 +328,26 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
 #pragma unroll
                 for (int m = 0; m < 8; ++m) s = MFMA(ak[rr][8 * hd + m], aq[rr][8 * hd + m], s);
                 // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
+                // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
+                //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
                 float mx = -INFINITY;
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
                     const int j = (m & 3) + 8 * (m >> 2) + 4 * h;
-                    s[m] = (j < n) ? s[m] * 0.25f : -INFINITY;
+                    s[m] = (j < n) ? s[m] : -INFINITY;
                     mx = fmaxf(mx, s[m]);
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 float sum = 0.0f;
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
-                    s[m] = expf(s[m] - mx);
+                    s[m] = __builtin_amdgcn_exp2f((s[m] - mx) * 0.36067376022224085f);
                     sum += s[m];
                 }
                 sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) s[m] = s[m] / sum;
+                for (int m = 0; m < 16; ++m) s[m] = s[m] * inv;
                 // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7
                 f32x16 o = zero16();
 #pragma unroll
@@ -291,11 +370,11 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
             f32x16 acc[ROWS];
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
-            gemm_t<ROWS, 16>(reinterpret_cast<const f32x4 *>(PB + PKB_WC + w * 16 * 256) + lane, xb_lane, XROW, acc);
+            gemm_t<ROWS>(ring, xb_lane, XROW, acc);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = 32 * w + 8 * g + 4 * h;
-                const f32x4 bb = *reinterpret_cast<const f32x4 *>(PB + PKB_BC + f);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(PV + PKV_BC + f);
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) {
                     float *xp = XA + rr * XROW + q * LDX + f;
@@ -317,12 +396,11 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
                 f32x16 ah[ROWS];
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
-                gemm_t<ROWS, 16>(reinterpret_cast<const f32x4 *>(PB + PKB_W1 + (4 * hc + w) * 16 * 256) + lane, xa_lane,
-                                 XROW, ah);
+                gemm_t<ROWS>(ring, xa_lane, XROW, ah);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f = 32 * w + 8 * g + 4 * h;
-                    const f32x4 bb = *reinterpret_cast<const f32x4 *>(PB + PKB_B1 + 128 * hc + f);
+                    const f32x4 bb = *reinterpret_cast<const f32x4 *>(PV + PKV_B1 + 128 * hc + f);
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) {
                         f32x4 v;
@@ -332,14 +410,13 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
                     }
                 }
                 __syncthreads();
-                gemm_t<ROWS, 16>(reinterpret_cast<const f32x4 *>(PB + PKB_W2 + (w * 64 + 16 * hc) * 256) + lane, xb_lane,
-                                 XROW, af);
+                gemm_t<ROWS>(ring, xb_lane, XROW, af);
                 __syncthreads();
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = 32 * w + 8 * g + 4 * h;
-                const f32x4 bb = *reinterpret_cast<const f32x4 *>(PB + PKB_B2 + f);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(PV + PKV_B2 + f);
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) {
                     float *xp = XA + rr * XROW + q * LDX + f;
@@ -470,7 +547,9 @@ extern "C" int dgl_policy_forward(const float *packed_weights, const dgl_policy_
                   DGL_TILE_STRIDE);
     // two rows per workgroup share every weight fragment; a single row per workgroup
     // keeps all 256 CUs busy when there are few rows
-    if (io->R >= 512) return launch_policy<2>(packed_weights, io, (hipStream_t)stream);
+    static const int forced = getenv("DGL_POLICY_ROWS") ? atoi(getenv("DGL_POLICY_ROWS")) : 0;
+    const int rows = forced ? forced : (io->R >= 512 ? 2 : 1);
+    if (rows == 2) return launch_policy<2>(packed_weights, io, (hipStream_t)stream);
     return launch_policy<1>(packed_weights, io, (hipStream_t)stream);
 }
 
