@@ -109,6 +109,58 @@ __device__ __forceinline__ void wave_emit_selected(const float *keys, int n, int
     }
 }
 
+// The k nearest of a row whose keys are SQUARED distances (the radicands of dgl_sqrt), ranked as
+// the reference ranks them: by the rounded square root, lowest index first among equal roots
+// (several neighbouring radicands share one root).  emit(j, rank) is called once per selected node,
+// rank ascending with j, by an arbitrary lane.  keys[] may be overwritten.  scratch: 128 words.
+//   fast path - the k-th smallest lane minimum bounds the k-th smallest radicand from above; every
+//               radicand whose root can tie with it lies within a few ulps of that bound, so the
+//               bound is raised by 4 ulps, the few keys below it are compacted (in index order)
+//               to one per lane, rooted, and ranked with one in-register sort and two ballots;
+//   general   - all keys are rooted in place, then bisection + the two ballot scans above.
+template <class Emit>
+__device__ __forceinline__ void wave_select_nearest(float *keys, int n, int k, float lane_min, float *scratch,
+                                                    Emit emit) {
+    const int lane = threadIdx.x & 63;
+    if (k <= 64) {
+        float bound = __shfl(wave_sort64(lane_min), k - 1, 64);
+        bound = __uint_as_float(__float_as_uint(bound) + 4u);      // +inf turns into NaN: no fast path
+        if (bound < INFINITY) {
+            int *cand_j = reinterpret_cast<int *>(scratch) + 64;
+            int c = 0;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                const float key = j < n ? keys[j] : INFINITY;
+                const bool p = key <= bound;
+                const unsigned long long m = __ballot(p);
+                const int pos = c + lane_rank(m);
+                if (p && pos < 64) {
+                    scratch[pos] = key;
+                    cand_j[pos] = j;
+                }
+                c += __popcll(m);
+            }
+            if (c <= 64) {
+                wave_lds_sync();
+                const float d = lane < c ? dgl_sqrt(scratch[lane]) : INFINITY;
+                const int j = cand_j[lane];
+                const float T = __shfl(wave_sort64(d), k - 1, 64);
+                const bool lt = d < T, eq = d == T;
+                const unsigned long long meq = __ballot(eq);
+                const int need_eq = k - __popcll(__ballot(lt));
+                const bool pick = lt || (eq && lane_rank(meq) < need_eq);
+                const unsigned long long mp = __ballot(pick);
+                if (pick) emit(j, lane_rank(mp));
+                return;
+            }
+        }
+    }
+    for (int j = lane; j < n; j += 64) keys[j] = dgl_sqrt(keys[j]);    // each lane roots the keys it wrote
+    wave_lds_sync();
+    const float T = wave_kth_smallest(keys, n, k, INFINITY, scratch);
+    wave_emit_selected(keys, n, k, T, emit);
+}
+
 // Per-column min-max normalisation of a token tile held in LDS ([n][stride] floats,
 // columns 0..ncol-1), written to global memory with the same stride:
 //   out = range != 0 ? (v - min) / range : 0      (TSP/TSPModel.py:158-172)

@@ -19,25 +19,33 @@ __global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
 }
 
 // ---------------------------------------------------------------------------- step
-// One wave per row.  LDS per wave: keys[N] + tile[(knn+1)*STRIDE] + scratch[64].
+// One wave per row.  LDS per wave: keys[N] + tile[(knn+1)*STRIDE] + scratch[128].
 struct TspRowCtx {
     const float *xyb;
     float xc, yc, nc, xs, ys, ns;
     size_t rowN;
 };
 
-__device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
-    const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-    const float ds = dgl_chain_dist(x, y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
+// x, y, d(j,cur), sin/cos towards the start node of node j (the avg/sd columns come from the state)
+__device__ __forceinline__ void tsp_geometry(const TspRowCtx &cx, int j, float *f) {
+    const float2 p = reinterpret_cast<const float2 *>(cx.xyb)[j];
+    const float nj = dgl_sqnorm(p.x, p.y);
+    const float ds = dgl_chain_dist(p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
     const float den = __fadd_rn(ds, 1e-7f);
-    f[0] = x;
-    f[1] = y;
-    f[2] = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);                  // d(j, current)
+    f[0] = p.x;
+    f[1] = p.y;
+    f[2] = dgl_chain_dist(p.x, p.y, nj, cx.xc, cx.yc, cx.nc);                  // d(j, current)
+    f[5] = __fdiv_rn(__fsub_rn(cx.ys, p.y), den);
+    f[6] = __fdiv_rn(__fsub_rn(cx.xs, p.x), den);
+}
+
+__device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
+    tsp_geometry(cx, j, f);
     f[3] = st.avg[cx.rowN + j];
     f[4] = st.sd[cx.rowN + j];
-    f[5] = __fdiv_rn(__fsub_rn(cx.ys, y), den);
-    f[6] = __fdiv_rn(__fsub_rn(cx.xs, x), den);
 }
+
+#define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
 
 template <int WAVES, bool UPDATE>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
@@ -62,33 +70,49 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
 
     const int u = N - t;                                    // unvisited after this step
-    const float up1 = (float)(u + 1), uf = (float)u;
+    const float up1 = (float)(u + 1);
+    const DglConstDiv du = dgl_const_div((float)u);
     const bool want_knn = (idx_out != nullptr) && (t < N);
     float lane_min = INFINITY;
     uint64_t *vis = st.visited + (size_t)r * W;
-    for (int j0 = 0; j0 < N; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long word = vis[j0 >> 6];      // same address for the whole wave
-        if (j < N) {
-            const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-            if (UPDATE) {
-                const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);    // dis[j][cur]
-                const float a0 = st.avg[cx.rowN + j], s0 = st.sd[cx.rowN + j];
-                // TSP/TSPEnv.py:386, 408-409
-                const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);
-                const float e = __fsub_rn(dcol, a0);
-                const float s1 = sqrtf(__fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf));
-                st.avg[cx.rowN + j] = a1;
-                st.sd[cx.rowN + j] = s1;
-            }
-            if (want_knn) {
-                const float drow = dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
-                const bool visited = ((word >> (j & 63)) & 1ull) || (j == cur);
-                // the reference adds 1e2 to visited keys; they can never rank among the
-                // k <= #unvisited smallest, so they are simply excluded here
-                const float key = visited ? INFINITY : drow;
-                keys[j] = key;
-                lane_min = fminf(lane_min, key);
+    const float2 *xy2 = reinterpret_cast<const float2 *>(cx.xyb);
+    float *avg = st.avg + cx.rowN, *sd = st.sd + cx.rowN;
+    for (int j0 = 0; j0 < N; j0 += 64 * STEP_UNROLL) {
+        float2 p[STEP_UNROLL];
+        float a0[STEP_UNROLL], s0[STEP_UNROLL];
+        unsigned long long word[STEP_UNROLL];
+        // all loads of the STEP_UNROLL chunks first (clamped addresses keep them unconditional)
+#pragma unroll
+        for (int q = 0; q < STEP_UNROLL; ++q) {
+            const int j = min(j0 + 64 * q + lane, N - 1);
+            p[q] = xy2[j];
+            if (UPDATE) { a0[q] = avg[j]; s0[q] = sd[j]; }
+            word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
+        }
+#pragma unroll
+        for (int q = 0; q < STEP_UNROLL; ++q) {
+            const int j = j0 + 64 * q + lane;
+            if (j < N) {
+                const float x = p[q].x, y = p[q].y, nj = dgl_sqnorm(x, y);
+                const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
+                if (UPDATE) {
+                    const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));          // dis[j][cur]
+                    // TSP/TSPEnv.py:386, 408-409
+                    const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0[q], up1), dcol), du);
+                    const float e = __fsub_rn(dcol, a0[q]);
+                    const float s1 = dgl_sqrt(dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0[q], s0[q]), up1), __fmul_rn(e, e)), du));
+                    avg[j] = a1;
+                    sd[j] = s1;
+                }
+                if (want_knn) {
+                    const bool visited = ((word[q] >> (j & 63)) & 1ull) || (j == cur);
+                    // key = dis[cur][j]^2; the root is taken for the few candidates only.  The reference
+                    // adds 1e2 to visited keys; they can never rank among the k <= #unvisited smallest,
+                    // so they are simply excluded here
+                    const float key = visited ? INFINITY : dgl_chain_sq(cross, cx.nc, nj);
+                    keys[j] = key;
+                    lane_min = fminf(lane_min, key);
+                }
             }
         }
     }
@@ -98,17 +122,30 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     }
     if (!want_knn) return;
 
-    wave_lds_sync();
+    // LDS keys of all lanes, and (for the staging loads below) the avg/sd stores of all lanes
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     const int k = min(knn, u);
-    const float T = wave_kth_smallest(keys, N, k, lane_min, scratch);
     int32_t *idx_row = idx_out + (size_t)r * knn;
-    wave_emit_selected(keys, N, k, T, [&](int j, int rank) {
+    // index, avg and sd of each selected node are staged here; the geometry columns are filled one
+    // token per lane below
+    auto stage = [&](int j, int tk) {
+        float *f = tile + tk * DGL_TILE_STRIDE;
+        f[3] = avg[j];
+        f[4] = sd[j];
+        f[DGL_TILE_STRIDE - 1] = __int_as_float(j);
+    };
+    wave_select_nearest(keys, N, k, lane_min, scratch, [&](int j, int rank) {
         idx_row[rank] = j;
-        tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+        stage(j, rank);
     });
     for (int e = k + lane; e < knn; e += 64) idx_row[e] = -1;
-    // the lane that updated avg/sd of `cur` also reads them back (same-thread ordering)
-    if (lane == (cur & 63)) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+    if (lane == 0) stage(cur, k);
+    wave_lds_sync();
+    for (int tk = lane; tk <= k; tk += 64) {
+        float *f = tile + tk * DGL_TILE_STRIDE;
+        tsp_geometry(cx, __float_as_int(f[DGL_TILE_STRIDE - 1]), f);
+    }
     wave_lds_sync();
     float *tout = tile_out + (size_t)r * (knn + 1) * DGL_TILE_STRIDE;
     wave_minmax_norm_store(tile, k + 1, TSP_F, DGL_TILE_STRIDE, tout);
@@ -198,7 +235,7 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
 template <bool UPDATE>
 static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
                            float *tile_out, dgl_stream_t stream, const char *what) {
-    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 64;
+    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     if (lds4 <= 64 * 1024) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
