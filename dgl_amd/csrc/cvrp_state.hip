@@ -24,21 +24,31 @@ struct CvrpRowCtx {
     size_t rowM;
 };
 
-// raw data row of node j (CVRP/CVRPEnv.py:696,718,746,782,801)
-__device__ __forceinline__ void cvrp_features(const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
-    const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-    const float d0 = dgl_chain_dist(x, y, nj, cx.x0, cx.y0, cx.n0);        // d(j, depot)
+// raw data row of a node at p with demand dem and running statistics (a, sd)
+// (CVRP/CVRPEnv.py:696,718,746,782,801); returns d(j, depot)
+__device__ __forceinline__ float cvrp_row(const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
+    const float nj = dgl_sqnorm(p.x, p.y);
+    const float d0 = dgl_chain_dist(p.x, p.y, nj, cx.x0, cx.y0, cx.n0);    // d(j, depot)
     const float den = __fadd_rn(d0, 1e-7f);
-    f[0] = x;
-    f[1] = y;
-    f[2] = cx.demb[j];
-    f[3] = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);                   // d(j, current)
-    f[4] = st.avg[cx.rowM + j];
-    f[5] = st.sd[cx.rowM + j];
-    f[6] = __fdiv_rn(__fsub_rn(cx.y0, y), den);
-    f[7] = __fdiv_rn(__fsub_rn(cx.x0, x), den);
+    f[0] = p.x;
+    f[1] = p.y;
+    f[2] = dem;
+    f[3] = dgl_chain_dist(p.x, p.y, nj, cx.xc, cx.yc, cx.nc);               // d(j, current)
+    f[4] = a;
+    f[5] = sd;
+    f[6] = __fdiv_rn(__fsub_rn(cx.y0, p.y), den);
+    f[7] = __fdiv_rn(__fsub_rn(cx.x0, p.x), den);
+    return d0;
 }
 
+__device__ __forceinline__ float cvrp_features(const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
+    return cvrp_row(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], cx.demb[j], st.avg[cx.rowM + j],
+                    st.sd[cx.rowM + j], f);
+}
+
+#define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
+
+// One wave per row.  LDS per wave: keysL[M] + keysD[M] + tile[(knn+depot_knn+2)*STRIDE] + scratch[128].
 template <int WAVES, bool UPDATE>
 __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
@@ -74,34 +84,62 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
     cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
 
-    const int u = M - t;                                       // CVRP/CVRPEnv.py:662
-    const float up1 = (float)(u + 1), uf = (float)u;
+    const int u = M - t;                                       // CVRP/CVRPEnv.py:662 (>= 1: t <= N)
+    const float up1 = (float)(u + 1);
+    const DglConstDiv du = dgl_const_div((float)u);
     const bool want_knn = (idx_last_out != nullptr) && (t < N);
     float minL = INFINITY, minD = INFINITY;
     uint64_t *vis = st.visited + (size_t)r * W;
-    for (int j0 = 0; j0 < M; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long word = vis[j0 >> 6];
-        if (j < M) {
-            const float x = cx.xyb[2 * j], y = cx.xyb[2 * j + 1], nj = dgl_sqnorm(x, y);
-            if (UPDATE) {
-                const float dcol = dgl_chain_dist(x, y, nj, cx.xc, cx.yc, cx.nc);
-                const float a0 = st.avg[cx.rowM + j], s0 = st.sd[cx.rowM + j];
-                const float a1 = __fdiv_rn(__fsub_rn(__fmul_rn(a0, up1), dcol), uf);            // :711
-                const float e = __fsub_rn(dcol, a0);
-                float item = __fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), uf);   // :733
-                if (item < 0.0f) item = 0.0f;                                                     // :735-736
-                st.avg[cx.rowM + j] = a1;
-                st.sd[cx.rowM + j] = sqrtf(item);
-            }
-            if (want_knn) {
-                const bool out = ((word >> (j & 63)) & 1ull) || (j == cur) || (j == 0);
-                const float kl = out ? INFINITY : dgl_chain_dist(cx.xc, cx.yc, cx.nc, x, y, nj);   // dis[cur][j]
-                const float kd = out ? INFINITY : dgl_chain_dist(cx.x0, cx.y0, cx.n0, x, y, nj);   // dis[0][j]
-                keysL[j] = kl;
-                keysD[j] = kd;
-                minL = fminf(minL, kl);
-                minD = fminf(minD, kd);
+    const float2 *xy2 = reinterpret_cast<const float2 *>(cx.xyb);
+    float *avg = st.avg + cx.rowM, *sd = st.sd + cx.rowM;
+    // The loads of a group of STEP_UNROLL chunks are issued one group ahead of its arithmetic
+    // (clamped addresses keep them unconditional).
+    struct Group {
+        float2 p[STEP_UNROLL];
+        float a0[STEP_UNROLL], s0[STEP_UNROLL];
+        unsigned long long word[STEP_UNROLL];
+    };
+    auto request = [&](int j0, Group &g) {
+#pragma unroll
+        for (int q = 0; q < STEP_UNROLL; ++q) {
+            const int j = min(j0 + 64 * q + lane, M - 1);
+            g.p[q] = xy2[j];
+            if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
+            g.word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
+        }
+    };
+    Group nxt;
+    request(0, nxt);
+    for (int j0 = 0; j0 < M; j0 += 64 * STEP_UNROLL) {
+        const Group g = nxt;
+        if (j0 + 64 * STEP_UNROLL < M) request(j0 + 64 * STEP_UNROLL, nxt);
+#pragma unroll
+        for (int q = 0; q < STEP_UNROLL; ++q) {
+            const int j = j0 + 64 * q + lane;
+            if (j < M) {
+                const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
+                const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
+                if (UPDATE) {
+                    const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));                  // dis[j][cur]
+                    const float a0 = g.a0[q], s0 = g.s0[q];
+                    const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);             // :711
+                    const float e = __fsub_rn(dcol, a0);
+                    float item = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
+                    if (item < 0.0f) item = 0.0f;                                                   // :735-736
+                    avg[j] = a1;
+                    sd[j] = dgl_sqrt(item);
+                }
+                if (want_knn) {
+                    // keys are squared distances dis[cur][j]^2 and dis[0][j]^2; visited nodes, the current
+                    // node and the depot never rank (the reference adds 1e2 to them, CVRP/CVRPModel.py:112-119)
+                    const bool out = ((g.word[q] >> (j & 63)) & 1ull) || (j == cur) || (j == 0);
+                    const float kl = out ? INFINITY : dgl_chain_sq(cross, cx.nc, nj);
+                    const float kd = out ? INFINITY : dgl_chain_sq(dgl_chain_cross(cx.x0, cx.y0, x, y), cx.n0, nj);
+                    keysL[j] = kl;
+                    keysD[j] = kd;
+                    minL = fminf(minL, kl);
+                    minD = fminf(minD, kd);
+                }
             }
         }
     }
@@ -120,7 +158,9 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     }
     if (!want_knn) return;
 
-    wave_lds_sync();
+    // LDS keys of all lanes, and (for the feature loads below) the avg/sd stores of all lanes
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     const int kd = min(depot_knn, N - t);                      // CVRP/CVRPModel.py:58,88
     const int kl = min(knn, kd);                               // :123
     const bool low = cap < 0.00001f;
@@ -129,41 +169,79 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     uint8_t *inf_row = infeasible_out + (size_t)r * knn;
     float *tileL = tile, *tileD = tile + (kl + 1) * DGL_TILE_STRIDE;
 
-    const float TL = wave_kth_smallest(keysL, M, kl, minL, scratch);
-    wave_emit_selected(keysL, M, kl, TL, [&](int j, int rank) {
-        il[rank] = j;
-        float *f = tileL + rank * DGL_TILE_STRIDE;
-        cvrp_features(st, cx, j, f);
-        inf_row[rank] = cap_eps < f[2] ? 1 : 0;                                   // CVRP/CVRPEnv.py:634
-        f[2] = low ? 1.1f : __fdiv_rn(f[2], cap);                                 // CVRP/CVRPModel.py:172-174
-    });
+    // neighbourhood of the current node: feasibility flag and demand / capacity (CVRP/CVRPEnv.py:634,
+    // CVRP/CVRPModel.py:172-174)
+    auto finish_last = [&](float *f, int rank) {
+        inf_row[rank] = cap_eps < f[2] ? 1 : 0;
+        f[2] = low ? 1.1f : __fdiv_rn(f[2], cap);
+    };
+    float ckey;
+    int cj;
+    int c = wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
+    if (c >= 0) {
+        // inputs of every candidate's row (and of the anchor, on lane 63 when it holds no candidate)
+        // are requested before the ranking bisection
+        const bool anchor_early = (c < 64) && (lane == 63);
+        const int jl = anchor_early ? cur : cj;
+        const float2 p = xy2[jl];
+        const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
+        int rank;
+        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kl, &rank);
+        if (pick || anchor_early) {
+            float *f = tileL + (pick ? rank : kl) * DGL_TILE_STRIDE;
+            cvrp_row(cx, p, dm, av, sv, f);
+            if (pick) {
+                il[rank] = cj;
+                finish_last(f, rank);
+            }
+        }
+        if (c == 64 && lane == 63) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+    } else {
+        wave_select_general(keysL, M, kl, scratch, [&](int j, int rank) {
+            il[rank] = j;
+            float *f = tileL + rank * DGL_TILE_STRIDE;
+            cvrp_features(st, cx, j, f);
+            finish_last(f, rank);
+        });
+        if (lane == 63) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+    }
     wave_lds_sync();                                           // scratch is reused by the second search
-    const float TD = wave_kth_smallest(keysD, M, kd, minD, scratch);
-    wave_emit_selected(keysD, M, kd, TD, [&](int j, int rank) {
-        id[rank] = j;
-        float *f = tileD + rank * DGL_TILE_STRIDE;
-        cvrp_features(st, cx, j, f);
-        const float x = f[0], y = f[1];
-        f[3] = dgl_chain_dist(x, y, dgl_sqnorm(x, y), cx.x0, cx.y0, cx.n0);      // distance_to_depot, :180-183
-    });
+    // neighbourhood of the depot: column 3 holds distance_to_depot (CVRP/CVRPModel.py:180-183)
+    c = wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj);
+    if (c >= 0) {
+        const bool anchor_early = (c < 64) && (lane == 63);
+        const int jl = anchor_early ? 0 : cj;
+        const float2 p = xy2[jl];
+        const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
+        int rank;
+        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kd, &rank);
+        if (pick || anchor_early) {
+            float *f = tileD + (pick ? rank : kd) * DGL_TILE_STRIDE;
+            const float d0 = cvrp_row(cx, p, dm, av, sv, f);
+            if (pick) {
+                id[rank] = cj;
+                f[3] = d0;
+            }
+        }
+        if (c == 64 && lane == 63) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+    } else {
+        wave_select_general(keysD, M, kd, scratch, [&](int j, int rank) {
+            id[rank] = j;
+            float *f = tileD + rank * DGL_TILE_STRIDE;
+            f[3] = cvrp_features(st, cx, j, f);
+        });
+        if (lane == 63) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+    }
     for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
     for (int e = kd + lane; e < depot_knn; e += 64) id[e] = -1;
-    // anchors: the current node closes the first group, the depot the second.  Each is written by
-    // the lane that updated that node's avg/sd above (same-thread store -> load ordering).
-    if (lane == (cur & 63)) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
-    if (lane == 0) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     wave_lds_sync();
 
     float *tout = tile_out + (size_t)r * (knn + depot_knn + 2) * DGL_TILE_STRIDE;
     float *toutD = tout + (kl + 1) * DGL_TILE_STRIDE;
-    wave_minmax_norm_store(tileL, kl + 1, CVRP_F, DGL_TILE_STRIDE, tout);        // CVRP/CVRPModel.py:299
-    wave_minmax_norm_store(tileD, kd + 1, CVRP_F, DGL_TILE_STRIDE, toutD);       // :301
-    // group flag (:303-304) and padding columns
-    const int ntok = kl + kd + 2;
-    for (int e = lane; e < ntok * (DGL_TILE_STRIDE - CVRP_F); e += 64) {
-        const int tk = e / (DGL_TILE_STRIDE - CVRP_F), c = CVRP_F + e % (DGL_TILE_STRIDE - CVRP_F);
-        tout[tk * DGL_TILE_STRIDE + c] = (c == CVRP_F && tk > kl) ? 1.0f : 0.0f;
-    }
+    // min-max per group (CVRP/CVRPModel.py:299,301); the column after the data is the group flag (:303-304)
+    wave_minmax_norm_store(tileL, kl + 1, CVRP_F, 0.0f, tout, scratch);
+    wave_lds_sync();                                           // scratch is reused
+    wave_minmax_norm_store(tileD, kd + 1, CVRP_F, 1.0f, toutD, scratch);
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
@@ -258,7 +336,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
                             int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
                             dgl_stream_t stream, const char *what) {
     const int M = st->N + 1;
-    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 64;
+    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     if (lds4 <= 64 * 1024) {
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,

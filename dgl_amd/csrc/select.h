@@ -4,15 +4,6 @@
 // must never be picked hold +inf.  The k smallest are chosen, the lowest index winning
 // among equal keys, and are emitted in ascending index order, so the result needs no
 // sort (the reference sorts its argsort prefix by index, TSP/TSPModel.py:89-91).
-//
-// Threshold search: T = k-th smallest key value.
-//   fast path  - each lane tracks the minimum of the keys it wrote; the k-th smallest of
-//                the 64 lane minima bounds T from above, the (few) keys below that bound
-//                are compacted to one per lane and sorted with an in-register bitonic
-//                network;
-//   general    - bisection on the key's bit pattern with ballot/popcount counting
-//                (31 passes over the keys), used when more than 64 keys survive the bound
-//                or k > 64.
 #pragma once
 #include "common.h"
 
@@ -23,50 +14,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ascending bitonic sort of one float per lane across the wave
-__device__ __forceinline__ float wave_sort64(float v) {
+// k-th smallest (1-based k, 1 <= k <= number of finite keys) of keys[0..n): bisection on the
+// key's bit pattern with ballot/popcount counting (31 passes over the keys).
+__device__ __forceinline__ float wave_kth_smallest(const float *keys, int n, int k, float *scratch) {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            float o = __shfl_xor(v, j, 64);
-            bool up = (lane & k) == 0;
-            bool lower = (lane & j) == 0;
-            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
-        }
-    }
-    return v;
-}
-
-// k-th smallest (1-based k, 1 <= k <= number of finite keys) of keys[0..n).
-// lane_min: minimum over the keys this lane itself stored (keys j with j % 64 == lane).
-// scratch: 64 floats of wave-private LDS.
-__device__ __forceinline__ float wave_kth_smallest(const float *keys, int n, int k, float lane_min,
-                                                   float *scratch) {
-    const int lane = threadIdx.x & 63;
-    if (k <= 64) {
-        float s = wave_sort64(lane_min);
-        float bound = __shfl(s, k - 1, 64);
-        if (bound < INFINITY) {
-            int c = 0;
-            for (int j0 = 0; j0 < n; j0 += 64) {
-                int j = j0 + lane;
-                float key = j < n ? keys[j] : INFINITY;
-                bool p = key <= bound;
-                unsigned long long m = __ballot(p);
-                int pos = c + lane_rank(m);
-                if (p && pos < 64) scratch[pos] = key;
-                c += __popcll(m);
-            }
-            if (c <= 64) {
-                wave_lds_sync();
-                float v = lane < c ? scratch[lane] : INFINITY;
-                v = wave_sort64(v);
-                return __shfl(v, k - 1, 64);
-            }
-        }
-    }
     unsigned res = 0;
     for (int bit = 30; bit >= 0; --bit) {
         unsigned cand = res | (1u << bit);
@@ -109,77 +60,151 @@ __device__ __forceinline__ void wave_emit_selected(const float *keys, int n, int
     }
 }
 
+// #{lanes : v <= x}, x given as the bit pattern of a non-negative float (wave-uniform)
+__device__ __forceinline__ int wave_count_le(float v, unsigned x) { return __popcll(__ballot(v <= __uint_as_float(x))); }
+
 // The k nearest of a row whose keys are SQUARED distances (the radicands of dgl_sqrt), ranked as
 // the reference ranks them: by the rounded square root, lowest index first among equal roots
-// (several neighbouring radicands share one root).  emit(j, rank) is called once per selected node,
-// rank ascending with j, by an arbitrary lane.  keys[] may be overwritten.  scratch: 128 words.
-//   fast path - the k-th smallest lane minimum bounds the k-th smallest radicand from above; every
-//               radicand whose root can tie with it lies within a few ulps of that bound, so the
-//               bound is raised by 4 ulps, the few keys below it are compacted (in index order)
-//               to one per lane, rooted, and ranked with one in-register sort and two ballots;
-//   general   - all keys are rooted in place, then bisection + the two ballot scans above.
-template <class Emit>
-__device__ __forceinline__ void wave_select_nearest(float *keys, int n, int k, float lane_min, float *scratch,
-                                                    Emit emit) {
+// (several neighbouring radicands share one root).  All searches are bisections on the bit
+// pattern of non-negative floats, driven by ballot counts: wave-uniform control flow, one vector
+// compare per probe, no cross-lane data movement.
+//
+// Step 1, wave_candidates: a bound B with at least k lane minima <= B (so at least k keys <= B),
+// found by a bisection that stops as soon as the count is within [k, k+2] (with m of the 64 lane
+// minima under B about -64 ln(1 - m/64) keys are: 40 for m = 30); every radicand whose root can
+// tie with that of a key <= B lies within 2 ulps above B, so B is raised by 4 ulps; the keys <= B
+// are compacted in index order, one per lane.  Returns their number c (lane < c holds key and
+// index j), or -1 when more than 64 keys lie under the bound or k > 64 (then use
+// wave_select_general).  scratch: 128 words.
+__device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, float lane_min, float *scratch,
+                                               float *key_out, int *j_out) {
     const int lane = threadIdx.x & 63;
-    if (k <= 64) {
-        float bound = __shfl(wave_sort64(lane_min), k - 1, 64);
-        bound = __uint_as_float(__float_as_uint(bound) + 4u);      // +inf turns into NaN: no fast path
-        if (bound < INFINITY) {
-            int *cand_j = reinterpret_cast<int *>(scratch) + 64;
-            int c = 0;
-            for (int j0 = 0; j0 < n; j0 += 64) {
-                const int j = j0 + lane;
-                const float key = j < n ? keys[j] : INFINITY;
-                const bool p = key <= bound;
-                const unsigned long long m = __ballot(p);
-                const int pos = c + lane_rank(m);
-                if (p && pos < 64) {
-                    scratch[pos] = key;
-                    cand_j[pos] = j;
-                }
-                c += __popcll(m);
-            }
-            if (c <= 64) {
-                wave_lds_sync();
-                const float d = lane < c ? dgl_sqrt(scratch[lane]) : INFINITY;
-                const int j = cand_j[lane];
-                const float T = __shfl(wave_sort64(d), k - 1, 64);
-                const bool lt = d < T, eq = d == T;
-                const unsigned long long meq = __ballot(eq);
-                const int need_eq = k - __popcll(__ballot(lt));
-                const bool pick = lt || (eq && lane_rank(meq) < need_eq);
-                const unsigned long long mp = __ballot(pick);
-                if (pick) emit(j, lane_rank(mp));
-                return;
+    const unsigned FMAX = 0x7F7FFFFFu;
+    if (k > 64) return -1;
+    unsigned hi = FMAX;                     // fewer than k finite lane minima: every finite key is a candidate
+    if (wave_count_le(lane_min, FMAX) >= k) {
+        unsigned lo = 0;
+        if (wave_count_le(lane_min, 0u) >= k) hi = 0;
+        while (hi - lo > 1) {               // invariant: count(lo) < k <= count(hi)
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            const int cnt = wave_count_le(lane_min, mid);
+            if (cnt >= k) {
+                hi = mid;
+                if (cnt <= k + 2) break;
+            } else {
+                lo = mid;
             }
         }
+        hi = min(hi + 4u, FMAX);
     }
+    const float bound = __uint_as_float(hi);
+    int *cand_j = reinterpret_cast<int *>(scratch) + 64;
+    int c = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        float key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // four LDS reads in flight
+            const int j = j0 + 64 * q + lane;
+            key[q] = j < n ? keys[j] : INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool p = key[q] <= bound;
+            const unsigned long long m = __ballot(p);
+            const int pos = c + lane_rank(m);
+            if (p && pos < 64) {
+                scratch[pos] = key[q];
+                cand_j[pos] = j0 + 64 * q + lane;
+            }
+            c += __popcll(m);
+        }
+    }
+    if (c > 64) return -1;
+    wave_lds_sync();
+    *key_out = lane < c ? scratch[lane] : INFINITY;
+    *j_out = lane < c ? cand_j[lane] : 0;
+    return c;
+}
+
+// Step 2, wave_pick_k: root = dgl_sqrt(key) of this lane's candidate (+inf for lane >= c).  Picks
+// the k smallest roots, the lower lane (= lower index) first among equal ones; returns whether
+// this lane's candidate is picked and its rank among the picks (ascending index).  The bisection
+// ends early when a probe separates exactly k candidates.
+__device__ __forceinline__ bool wave_pick_k(float root, int c, int k, int *rank_out) {
+    const int lane = threadIdx.x & 63;
+    bool pick = lane < c;
+    if (c > k) {
+        unsigned thi = 0x7F7FFFFFu, tlo = 0;                              // count(thi) = c > k
+        bool split = false;                                               // a probe with exactly k roots below it
+        if (wave_count_le(root, 0u) >= k) thi = 0;
+        while (thi - tlo > 1) {                                           // invariant: count(tlo) < k <= count(thi)
+            const unsigned mid = tlo + ((thi - tlo) >> 1);
+            const int cnt = wave_count_le(root, mid);
+            if (cnt >= k) thi = mid; else tlo = mid;
+            if (cnt == k) { split = true; break; }
+        }
+        const float T = __uint_as_float(thi);
+        if (split) {
+            pick = root <= T;
+        } else {                                                           // T = k-th smallest root, tied
+            const bool lt = root < T, eq = root == T;
+            const unsigned long long meq = __ballot(eq);
+            const int need_eq = k - __popcll(__ballot(lt));
+            pick = lt || (eq && lane_rank(meq) < need_eq);
+        }
+    }
+    *rank_out = lane_rank(__ballot(pick));
+    return pick;
+}
+
+// General path: all keys are rooted in place, then bisection over all keys + the two ballot scans
+// of wave_emit_selected.  emit(j, rank) is called by the lane that owns j (j % 64 == lane).
+template <class Emit>
+__device__ __forceinline__ void wave_select_general(float *keys, int n, int k, float *scratch, Emit emit) {
+    const int lane = threadIdx.x & 63;
     for (int j = lane; j < n; j += 64) keys[j] = dgl_sqrt(keys[j]);    // each lane roots the keys it wrote
     wave_lds_sync();
-    const float T = wave_kth_smallest(keys, n, k, INFINITY, scratch);
+    const float T = wave_kth_smallest(keys, n, k, scratch);
     wave_emit_selected(keys, n, k, T, emit);
 }
 
-// Per-column min-max normalisation of a token tile held in LDS ([n][stride] floats,
-// columns 0..ncol-1), written to global memory with the same stride:
+// Per-column min-max normalisation of a token tile held in LDS ([n][DGL_TILE_STRIDE] floats, data
+// in columns 0..ncol-1), written to global memory with the same stride:
 //   out = range != 0 ? (v - min) / range : 0      (TSP/TSPModel.py:158-172)
-__device__ __forceinline__ void wave_minmax_norm_store(const float *tile, int n, int ncol, int stride,
-                                                       float *out) {
+// Column ncol of the output receives `pad_first`, the remaining padding columns 0, so the consumer
+// can load whole strides.  Lane 12 g + c owns column c of the tokens g, g+5, g+10, ...: one store
+// instruction covers 5 whole tokens (240 contiguous bytes) and min, range and 1/range are fixed
+// per lane.  scratch: 128 words.
+__device__ __forceinline__ void wave_minmax_norm_store(const float *tile, int n, int ncol, float pad_first,
+                                                       float *out, float *scratch) {
+    static_assert(DGL_TILE_STRIDE == 12, "lane mapping assumes 5 tokens x 12 columns per wave instruction");
     const int lane = threadIdx.x & 63;
-    for (int c = 0; c < ncol; ++c) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int tk = lane; tk < n; tk += 64) {
-            float v = tile[tk * stride + c];
+    const int g = lane / DGL_TILE_STRIDE, c = lane - DGL_TILE_STRIDE * g;
+    const bool data = (g < 5) && (c < ncol);
+    float lo = INFINITY, hi = -INFINITY;
+    if (data) {
+        for (int tk = g; tk < n; tk += 5) {
+            const float v = tile[tk * DGL_TILE_STRIDE + c];
             lo = fminf(lo, v);
             hi = fmaxf(hi, v);
         }
-        lo = wave_min_f32(lo);
-        hi = wave_max_f32(hi);
-        float rng = __fsub_rn(hi, lo);
-        for (int tk = lane; tk < n; tk += 64) {
-            float v = tile[tk * stride + c];
-            out[tk * stride + c] = (rng != 0.0f) ? __fdiv_rn(__fsub_rn(v, lo), rng) : 0.0f;
+    }
+    scratch[lane] = lo;
+    scratch[64 + lane] = hi;
+    wave_lds_sync();
+    if (g < 5) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            lo = fminf(lo, scratch[DGL_TILE_STRIDE * q + c]);
+            hi = fmaxf(hi, scratch[64 + DGL_TILE_STRIDE * q + c]);
+        }
+        const float rng = __fsub_rn(hi, lo);
+        const DglConstDiv dv = dgl_const_div(rng);
+        const float pad = (c == ncol) ? pad_first : 0.0f;
+        for (int tk = g; tk < n; tk += 5) {
+            float o = pad;
+            if (data) o = (rng != 0.0f) ? dgl_div(__fsub_rn(tile[tk * DGL_TILE_STRIDE + c], lo), dv) : 0.0f;
+            out[tk * DGL_TILE_STRIDE + c] = o;
         }
     }
 }

@@ -26,23 +26,23 @@ struct TspRowCtx {
     size_t rowN;
 };
 
-// x, y, d(j,cur), sin/cos towards the start node of node j (the avg/sd columns come from the state)
-__device__ __forceinline__ void tsp_geometry(const TspRowCtx &cx, int j, float *f) {
-    const float2 p = reinterpret_cast<const float2 *>(cx.xyb)[j];
+// raw feature row of a node at p with running statistics (a, sd): x, y, d(j,cur), avg, sd and
+// sin/cos of the direction towards the start node (TSP/TSPEnv.py:371,393,415,430-475)
+__device__ __forceinline__ void tsp_row(const TspRowCtx &cx, float2 p, float a, float sd, float *f) {
     const float nj = dgl_sqnorm(p.x, p.y);
     const float ds = dgl_chain_dist(p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
     const float den = __fadd_rn(ds, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
     f[2] = dgl_chain_dist(p.x, p.y, nj, cx.xc, cx.yc, cx.nc);                  // d(j, current)
+    f[3] = a;
+    f[4] = sd;
     f[5] = __fdiv_rn(__fsub_rn(cx.ys, p.y), den);
     f[6] = __fdiv_rn(__fsub_rn(cx.xs, p.x), den);
 }
 
 __device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
-    tsp_geometry(cx, j, f);
-    f[3] = st.avg[cx.rowN + j];
-    f[4] = st.sd[cx.rowN + j];
+    tsp_row(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], st.avg[cx.rowN + j], st.sd[cx.rowN + j], f);
 }
 
 #define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
@@ -77,35 +77,46 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     uint64_t *vis = st.visited + (size_t)r * W;
     const float2 *xy2 = reinterpret_cast<const float2 *>(cx.xyb);
     float *avg = st.avg + cx.rowN, *sd = st.sd + cx.rowN;
-    for (int j0 = 0; j0 < N; j0 += 64 * STEP_UNROLL) {
+    // The loads of a group of STEP_UNROLL chunks are issued one group ahead of its arithmetic, so
+    // every wave keeps a group of requests in flight while it computes (clamped addresses keep the
+    // loads unconditional).
+    struct Group {
         float2 p[STEP_UNROLL];
         float a0[STEP_UNROLL], s0[STEP_UNROLL];
         unsigned long long word[STEP_UNROLL];
-        // all loads of the STEP_UNROLL chunks first (clamped addresses keep them unconditional)
+    };
+    auto request = [&](int j0, Group &g) {
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = min(j0 + 64 * q + lane, N - 1);
-            p[q] = xy2[j];
-            if (UPDATE) { a0[q] = avg[j]; s0[q] = sd[j]; }
-            word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
+            g.p[q] = xy2[j];
+            if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
+            g.word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
         }
+    };
+    Group nxt;
+    request(0, nxt);
+    for (int j0 = 0; j0 < N; j0 += 64 * STEP_UNROLL) {
+        const Group g = nxt;
+        if (j0 + 64 * STEP_UNROLL < N) request(j0 + 64 * STEP_UNROLL, nxt);
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             if (j < N) {
-                const float x = p[q].x, y = p[q].y, nj = dgl_sqnorm(x, y);
+                const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
                 const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
                     const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));          // dis[j][cur]
                     // TSP/TSPEnv.py:386, 408-409
-                    const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0[q], up1), dcol), du);
-                    const float e = __fsub_rn(dcol, a0[q]);
-                    const float s1 = dgl_sqrt(dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0[q], s0[q]), up1), __fmul_rn(e, e)), du));
+                    const float a0 = g.a0[q], s0 = g.s0[q];
+                    const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);
+                    const float e = __fsub_rn(dcol, a0);
+                    const float s1 = dgl_sqrt(dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du));
                     avg[j] = a1;
                     sd[j] = s1;
                 }
                 if (want_knn) {
-                    const bool visited = ((word[q] >> (j & 63)) & 1ull) || (j == cur);
+                    const bool visited = ((g.word[q] >> (j & 63)) & 1ull) || (j == cur);
                     // key = dis[cur][j]^2; the root is taken for the few candidates only.  The reference
                     // adds 1e2 to visited keys; they can never rank among the k <= #unvisited smallest,
                     // so they are simply excluded here
@@ -127,33 +138,31 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     __builtin_amdgcn_wave_barrier();
     const int k = min(knn, u);
     int32_t *idx_row = idx_out + (size_t)r * knn;
-    // index, avg and sd of each selected node are staged here; the geometry columns are filled one
-    // token per lane below
-    auto stage = [&](int j, int tk) {
-        float *f = tile + tk * DGL_TILE_STRIDE;
-        f[3] = avg[j];
-        f[4] = sd[j];
-        f[DGL_TILE_STRIDE - 1] = __int_as_float(j);
-    };
-    wave_select_nearest(keys, N, k, lane_min, scratch, [&](int j, int rank) {
-        idx_row[rank] = j;
-        stage(j, rank);
-    });
+    float ckey;
+    int cj;
+    const int c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+    if (c >= 0) {
+        // The inputs of every candidate's feature row (and of the anchor token = the current node, on
+        // lane 63 when that lane holds no candidate) are requested before the ranking bisection.
+        const bool anchor_early = (c < 64) && (lane == 63);
+        const int jl = anchor_early ? cur : cj;
+        const float2 p = xy2[jl];
+        const float av = avg[jl], sv = sd[jl];
+        int rank;
+        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, k, &rank);
+        if (pick) idx_row[rank] = cj;
+        if (pick || anchor_early) tsp_row(cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+    } else {
+        wave_select_general(keys, N, k, scratch, [&](int j, int rank) {
+            idx_row[rank] = j;
+            tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+        });
+        if (lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+    }
     for (int e = k + lane; e < knn; e += 64) idx_row[e] = -1;
-    if (lane == 0) stage(cur, k);
     wave_lds_sync();
-    for (int tk = lane; tk <= k; tk += 64) {
-        float *f = tile + tk * DGL_TILE_STRIDE;
-        tsp_geometry(cx, __float_as_int(f[DGL_TILE_STRIDE - 1]), f);
-    }
-    wave_lds_sync();
-    float *tout = tile_out + (size_t)r * (knn + 1) * DGL_TILE_STRIDE;
-    wave_minmax_norm_store(tile, k + 1, TSP_F, DGL_TILE_STRIDE, tout);
-    // zero the padding columns so the policy kernel can load whole strides
-    for (int e = lane; e < (k + 1) * (DGL_TILE_STRIDE - TSP_F); e += 64) {
-        int tk = e / (DGL_TILE_STRIDE - TSP_F), c = TSP_F + e % (DGL_TILE_STRIDE - TSP_F);
-        tout[tk * DGL_TILE_STRIDE + c] = 0.0f;
-    }
+    wave_minmax_norm_store(tile, k + 1, TSP_F, 0.0f, tile_out + (size_t)r * (knn + 1) * DGL_TILE_STRIDE, scratch);
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
