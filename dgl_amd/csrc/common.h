@@ -79,6 +79,18 @@ __device__ __forceinline__ float dgl_chain_dist(float xi, float yi, float ni, fl
     return dgl_sqrt(dgl_chain_sq(dgl_chain_cross(xi, yi, xj, yj), ni, nj));
 }
 
+// v for the lanes whose bit is clear in the wave-uniform mask, +inf for the others: the mask
+// serves directly as the condition register of one v_cndmask.
+__device__ __forceinline__ float dgl_inf_where(unsigned long long mask, float v) {
+    return __builtin_amdgcn_inverse_ballot_w64(mask) ? INFINITY : v;
+}
+// 64-bit word held by lane `src` (wave-uniform index) of a per-lane value
+__device__ __forceinline__ unsigned long long dgl_readlane_u64(unsigned long long v, int src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

@@ -73,9 +73,9 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     cx.rowM = (size_t)r * M;
 
     // ---- action decoding, capacity (CVRP/CVRPEnv.py:612-631)
-    const int act = UPDATE ? action[r] : 0;
+    const int act = UPDATE ? __builtin_amdgcn_readfirstlane(action[r]) : 0;     // wave-uniform: scalar registers
     const bool via = act > N;
-    const int cur = UPDATE ? (via ? act - (N + 1) : act) : st.nodes[(size_t)r * N + (t - 1)];
+    const int cur = UPDATE ? (via ? act - (N + 1) : act) : __builtin_amdgcn_readfirstlane(st.nodes[(size_t)r * N + (t - 1)]);
     const float dem_cur = cx.demb[cur];
     const float cap_old = st.capacity[r];
     float cap = !UPDATE ? cap_old : (via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur));
@@ -97,7 +97,6 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     struct Group {
         float2 p[STEP_UNROLL];
         float a0[STEP_UNROLL], s0[STEP_UNROLL];
-        unsigned long long word[STEP_UNROLL];
     };
     auto request = [&](int j0, Group &g) {
 #pragma unroll
@@ -105,14 +104,17 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
             const int j = min(j0 + 64 * q + lane, M - 1);
             g.p[q] = xy2[j];
             if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
-            g.word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
         }
     };
     Group nxt;
     request(0, nxt);
+    // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
+    // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
+    unsigned long long vis_words = 0;
     for (int j0 = 0; j0 < M; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < M) request(j0 + 64 * STEP_UNROLL, nxt);
+        if (want_knn && ((j0 >> 6) & 63) == 0) vis_words = vis[min((j0 >> 6) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
@@ -132,9 +134,12 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
                 if (want_knn) {
                     // keys are squared distances dis[cur][j]^2 and dis[0][j]^2; visited nodes, the current
                     // node and the depot never rank (the reference adds 1e2 to them, CVRP/CVRPModel.py:112-119)
-                    const bool out = ((g.word[q] >> (j & 63)) & 1ull) || (j == cur) || (j == 0);
-                    const float kl = out ? INFINITY : dgl_chain_sq(cross, cx.nc, nj);
-                    const float kd = out ? INFINITY : dgl_chain_sq(dgl_chain_cross(cx.x0, cx.y0, x, y), cx.n0, nj);
+                    const int chunk = (j0 >> 6) + q;
+                    unsigned long long excl = dgl_readlane_u64(vis_words, chunk & 63);
+                    if (chunk == (cur >> 6)) excl |= 1ull << (cur & 63);
+                    if (chunk == 0) excl |= 1ull;
+                    const float kl = dgl_inf_where(excl, dgl_chain_sq(cross, cx.nc, nj));
+                    const float kd = dgl_inf_where(excl, dgl_chain_sq(dgl_chain_cross(cx.x0, cx.y0, x, y), cx.n0, nj));
                     keysL[j] = kl;
                     keysD[j] = kd;
                     minL = fminf(minL, kl);
@@ -338,7 +343,8 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    if (lds4 <= 64 * 1024) {
+    // few rows: one wave per workgroup spreads them over all CUs
+    if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
                            per_wave);

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     TspRowCtx cx;
     cx.xyb = st.xy + (size_t)b * N * 2;
     cx.rowN = (size_t)r * N;
-    const int cur = UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)];
-    const int start = (t == 1) ? cur : st.tour[cx.rowN];
+    // wave-uniform values: kept in scalar registers
+    const int cur = __builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]);
+    const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(st.tour[cx.rowN]);
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
 
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     struct Group {
         float2 p[STEP_UNROLL];
         float a0[STEP_UNROLL], s0[STEP_UNROLL];
-        unsigned long long word[STEP_UNROLL];
     };
     auto request = [&](int j0, Group &g) {
 #pragma unroll
@@ -91,14 +91,17 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
             const int j = min(j0 + 64 * q + lane, N - 1);
             g.p[q] = xy2[j];
             if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
-            g.word[q] = vis[min((j0 >> 6) + q, W - 1)];      // same address for the whole wave
         }
     };
     Group nxt;
     request(0, nxt);
+    // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
+    // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
+    unsigned long long vis_words = 0;
     for (int j0 = 0; j0 < N; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < N) request(j0 + 64 * STEP_UNROLL, nxt);
+        if (want_knn && ((j0 >> 6) & 63) == 0) vis_words = vis[min((j0 >> 6) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
@@ -116,11 +119,13 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
                     sd[j] = s1;
                 }
                 if (want_knn) {
-                    const bool visited = ((g.word[q] >> (j & 63)) & 1ull) || (j == cur);
+                    const int chunk = (j0 >> 6) + q;
+                    unsigned long long excl = dgl_readlane_u64(vis_words, chunk & 63);
+                    if (chunk == (cur >> 6)) excl |= 1ull << (cur & 63);
                     // key = dis[cur][j]^2; the root is taken for the few candidates only.  The reference
                     // adds 1e2 to visited keys; they can never rank among the k <= #unvisited smallest,
                     // so they are simply excluded here
-                    const float key = visited ? INFINITY : dgl_chain_sq(cross, cx.nc, nj);
+                    const float key = dgl_inf_where(excl, dgl_chain_sq(cross, cx.nc, nj));
                     keys[j] = key;
                     lane_min = fminf(lane_min, key);
                 }
@@ -246,7 +251,8 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
                            float *tile_out, dgl_stream_t stream, const char *what) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    if (lds4 <= 64 * 1024) {
+    // few rows: one wave per workgroup spreads them over all CUs
+    if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, selected, t, knn, idx_out, tile_out, per_wave);
     } else {
