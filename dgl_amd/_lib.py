@@ -16,6 +16,8 @@ TILE_STRIDE = 12
 MAX_TOKENS = 32
 PROBLEM_TSP = 0
 PROBLEM_CVRP = 1
+ARITH_SPLIT_F16 = 0    # f16 split-operand matrix cores, f32 accumulate (default)
+ARITH_F32 = 1          # f32-input matrix instructions (bitwise FMA chains)
 
 
 class TspState(Structure):
@@ -43,6 +45,7 @@ class PolicyWeights(Structure):
 class PolicyIO(Structure):
     _fields_ = [("problem", c_int32), ("R", c_int32), ("n", c_int32), ("k_last", c_int32), ("N", c_int32),
                 ("idx_stride", c_int32), ("idx_dep_stride", c_int32), ("tile_row_stride", c_int32),
+                ("arithmetic", c_int32), ("reserved", c_int32),
                 ("tile", c_void_p), ("idx_last", c_void_p), ("idx_depot", c_void_p), ("infeasible", c_void_p),
                 ("logits_out", c_void_p), ("prob_out", c_void_p), ("selected_out", c_void_p)]
 

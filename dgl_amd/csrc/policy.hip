@@ -21,41 +21,10 @@
 // B operand: the attention needs no LDS traffic and no cross-lane shuffles beyond one
 // exchange between the two half-waves.
 #include <cstdlib>
-#include <type_traits>
 
-#include "common.h"
+#include "policy_layout.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define D_MODEL 128
-#define FF_DIM 512
 #define LDX 132                       // LDS row stride in floats
-#define EMB_IN DGL_TILE_STRIDE        // padded input features
-
-// ---- packed weight layout (float offsets) ---------------------------------------
-// Small vectors first, then one weight STREAM per wave: the 1 KB fragments (64 lanes x 16 B) a
-// wave consumes, in exactly the order it consumes them, so that a wave's weight traffic is one
-// linear read which a register ring prefetches PF fragments ahead across GEMM boundaries.
-//   per block : 48 fragments q,k,v interleaved by K-chunk; 16 combine; 4 x (16 W1 + 16 W2)
-//   stream    : block 0 | anchor embedding(s) 2 x 16 (TSP repeats its single one) | blocks 1..3
-#define PK_EMB_W 0
-#define PK_EMB_B (PK_EMB_W + D_MODEL * EMB_IN)
-#define PK_VEC0 (PK_EMB_B + D_MODEL)               // per block: bc[128] b1[512] b2[128]
-#define PKV_BC 0
-#define PKV_B1 (PKV_BC + D_MODEL)
-#define PKV_B2 (PKV_B1 + FF_DIM)
-#define PKV_SIZE (PKV_B2 + D_MODEL)
-#define PK_ANCHOR_B (PK_VEC0 + 4 * PKV_SIZE)       // [2][128]
-#define PK_FINAL_W (PK_ANCHOR_B + 2 * D_MODEL)
-#define PK_FINAL_B (PK_FINAL_W + D_MODEL)
-#define PK_STREAM0 (PK_FINAL_B + 4)
-#define FRAG 256                                    // floats per fragment
-#define BLK_FRAGS 192                               // fragments per wave per block
-#define ANCHOR_FRAGS 32
-#define WAVE_FRAGS (4 * BLK_FRAGS + ANCHOR_FRAGS)   // 800
-#define PF 8                                        // prefetch depth (fragments in flight per wave)
-#define PK_TOTAL (PK_STREAM0 + (4 * WAVE_FRAGS + PF) * FRAG)
 
 extern "C" int64_t dgl_policy_packed_floats(int32_t) { return PK_TOTAL; }
 
@@ -67,6 +36,20 @@ __global__ void pack_tile_kernel(const float *__restrict__ W, int IN, int ot, in
         const int e = o & 3, lane = (o >> 2) & 63, j = o >> 8;
         dst[(size_t)j * stride * FRAG + lane * 4 + e] =
             W[(size_t)(32 * ot + (lane & 31)) * IN + 8 * (c0 + j) + 4 * (lane >> 5) + e];
+    }
+}
+// f16 stream: fragment pair j (K-step s0 + j) of out tile `ot`:
+//   dst[(2j*stride + part)*512 + lane*8 + e] = part(W[32*ot + (lane&31)][16(s0+j) + 8(lane>>5) + e]),
+// part 0 = hi = binary16(W), part 1 = lo = binary16(W - hi)
+__global__ void pack_tile16_kernel(const float *__restrict__ W, int IN, int ot, int s0, int ns, _Float16 *__restrict__ dst,
+                                   int stride) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < ns * 512; o += gridDim.x * blockDim.x) {
+        const int e = o & 7, lane = (o >> 3) & 63, j = o >> 9;
+        const float w = W[(size_t)(32 * ot + (lane & 31)) * IN + 16 * (s0 + j) + 8 * (lane >> 5) + e];
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        dst[(size_t)(2 * j * stride) * 512 + lane * 8 + e] = hi;
+        dst[(size_t)(2 * j * stride + 1) * 512 + lane * 8 + e] = lo;
     }
 }
 __global__ void pack_copy_kernel(const float *__restrict__ src, int n, float *__restrict__ dst) {
@@ -95,6 +78,12 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
         hipLaunchKernelGGL(pack_tile_kernel, dim3(4), dim3(256), 0, s, W, IN, ot, c0, nc,
                            packed + PK_STREAM0 + frag * FRAG, stride);
     };
+    // f16 stream: `frag` = fragment index of the tile's first (hi) fragment, consecutive (hi, lo)
+    // pairs `stride` fragments apart
+    auto tile16 = [&](const float *W, int IN, int ot, int s0, int ns, size_t frag, int stride) {
+        hipLaunchKernelGGL(pack_tile16_kernel, dim3(4), dim3(256), 0, s, W, IN, ot, s0, ns,
+                           reinterpret_cast<_Float16 *>(packed + PK_STREAM16 + frag * FRAG), stride);
+    };
     auto vec = [&](const float *v, int n, int off) {
         hipLaunchKernelGGL(pack_copy_kernel, dim3(1), dim3(256), 0, s, v, n, packed + off);
     };
@@ -117,16 +106,27 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
             tile(k.wk, D_MODEL, wv, 0, 16, f + 1, 3);
             tile(k.wv, D_MODEL, wv, 0, 16, f + 2, 3);
             tile(k.wc, D_MODEL, wv, 0, 16, f + 48, 1);
+            // f16: per K-step q.hi q.lo k.hi k.lo v.hi v.lo
+            tile16(k.wq, D_MODEL, wv, 0, 8, f + 0, 3);
+            tile16(k.wk, D_MODEL, wv, 0, 8, f + 2, 3);
+            tile16(k.wv, D_MODEL, wv, 0, 8, f + 4, 3);
+            tile16(k.wc, D_MODEL, wv, 0, 8, f + 48, 1);
             for (int hc = 0; hc < 4; ++hc) {
                 tile(k.w1, D_MODEL, 4 * hc + wv, 0, 16, f + 64 + 32 * hc, 1);
                 tile(k.w2, FF_DIM, wv, 16 * hc, 16, f + 64 + 32 * hc + 16, 1);
+                tile16(k.w1, D_MODEL, 4 * hc + wv, 0, 8, f + 64 + 32 * hc, 1);
+                tile16(k.w2, FF_DIM, wv, 8 * hc, 8, f + 64 + 32 * hc + 16, 1);
             }
         }
-        for (int a = 0; a < 2; ++a)
-            tile(w->anchor_w[w->problem == DGL_PROBLEM_CVRP ? a : 0], D_MODEL, wv, 0, 16,
-                 (size_t)wv * WAVE_FRAGS + BLK_FRAGS + 16 * a, 1);
+        for (int a = 0; a < 2; ++a) {
+            const float *wa = w->anchor_w[w->problem == DGL_PROBLEM_CVRP ? a : 0];
+            tile(wa, D_MODEL, wv, 0, 16, (size_t)wv * WAVE_FRAGS + BLK_FRAGS + 16 * a, 1);
+            tile16(wa, D_MODEL, wv, 0, 8, (size_t)wv * WAVE_FRAGS + BLK_FRAGS + 16 * a, 1);
+        }
     }
-    vec(nullptr, PF * FRAG, PK_STREAM0 + 4 * WAVE_FRAGS * FRAG);      // zero tail the prefetch ring may read
+    // zero tails the prefetch rings may read
+    vec(nullptr, (PK_STREAM_FRAGS - 4 * WAVE_FRAGS) * FRAG, PK_STREAM0 + 4 * WAVE_FRAGS * FRAG);
+    vec(nullptr, (PK_STREAM_FRAGS - 4 * WAVE_FRAGS) * FRAG, PK_STREAM16 + 4 * WAVE_FRAGS * FRAG);
     DGL_CHECK_LAUNCH("dgl_policy_pack");
     return DGL_OK;
 }
@@ -134,46 +134,10 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
 // ---- device building blocks ----------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// Register ring holding the next PF weight fragments of this wave's stream.  take<SLOT>() returns
-// the oldest fragment and immediately re-issues the slot's load PF fragments ahead, so weight
-// loads stay in flight across MFMAs, epilogues and barriers.
-struct WeightRing {
-    f32x4 r[PF];
-    const f32x4 *next;      // this lane's 16 bytes of the next fragment to request
-    __device__ __forceinline__ void fill(const f32x4 *p) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) r[i] = p[i * 64];
-        next = p + PF * 64;
-    }
-    template <int SLOT>
-    __device__ __forceinline__ f32x4 take() {
-        const f32x4 v = r[SLOT];
-        r[SLOT] = *next;
-#ifndef EXP_SAMEFRAG
-        next += 64;
-#endif
-        return v;
-    }
-};
-
-template <int C, int N>
-struct Unroll {
-    template <class F>
-    static __device__ __forceinline__ void run(F &&f) {
-        f(std::integral_constant<int, C>{});
-        Unroll<C + 1, N>::run(f);
-    }
-};
-template <int N>
-struct Unroll<N, N> {
-    template <class F>
-    static __device__ __forceinline__ void run(F &&) {}
-};
-
 // acc[rr] += W(out tile) * X[rr]^T over 16 K-chunks (transposed product: lane = token,
 // registers = features).  xp: LDS pointer X[row 0][token q][4h]; xrow = floats between rows.
 template <int ROWS>
-__device__ __forceinline__ void gemm_t(WeightRing &ring, const float *xp, int xrow, f32x16 (&acc)[ROWS]) {
+__device__ __forceinline__ void gemm_t(WeightRing<PF> &ring, const float *xp, int xrow, f32x16 (&acc)[ROWS]) {
     // X operands are read from LDS one K-chunk ahead of the MFMAs that consume them, so the
     // ~100+ cycle LDS latency hides behind eight 64-cycle MFMAs instead of stalling each chunk.
     f32x4 xn[ROWS];
@@ -197,15 +161,8 @@ __device__ __forceinline__ void gemm_t(WeightRing &ring, const float *xp, int xr
     });
 }
 
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-    return z;
-}
-
 template <int ROWS>
-__global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P, dgl_policy_io_t io) {
+__global__ __launch_bounds__(256) void policy_kernel_f32(const float *__restrict__ P, dgl_policy_io_t io) {
     extern __shared__ float lds[];
     float *XA = lds;                           // [ROWS][32][LDX]
     float *XB = XA + ROWS * 32 * LDX;          // [ROWS][32][LDX]
@@ -215,7 +172,7 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
     const int n = io.n;
     constexpr int XROW = 32 * LDX;
 
-    WeightRing ring;
+    WeightRing<PF> ring;
     ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM0 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
 
     // ---- embedding: X[token][c] = b[c] + sum_f tile[token][f] * We[c][f] ----------
@@ -455,40 +412,10 @@ __global__ __launch_bounds__(256) void policy_kernel(const float *__restrict__ P
     for (int rr = w; rr < ROWS; rr += 4) {
         const int r = row0 + rr;
         if (r >= io.R) continue;
-        const int tok = q;                               // both half-waves compute the same values
         float logit = P[PK_FINAL_B];
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) logit += part[(ww * ROWS + rr) * 32 + tok];
-        bool cand = tok < n && tok != anchor0 && tok != anchor1;
-        bool open = cand;
-        if (io.problem == DGL_PROBLEM_CVRP && io.infeasible != nullptr && tok < io.k_last)
-            open = cand && (io.infeasible[(size_t)r * io.idx_stride + tok] == 0);
-        const float ml = open ? logit : -INFINITY;
-        const float mx = wave_max_f32(ml);
-        const float ex = open ? expf(ml - mx) : 0.0f;
-        float sum = ex;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);   // within a 32-lane half
-        float p = ex / sum;
-        if (p <= 1e-5f) p = p + 1e-7f;                   // TSP/TSPModel.py:323-325
-        if (!cand) p = 0.0f;
-        if (h == 0) {
-            if (io.logits_out) io.logits_out[(size_t)r * DGL_MAX_TOKENS + tok] = tok < n ? logit : 0.0f;
-            if (io.prob_out) io.prob_out[(size_t)r * DGL_MAX_TOKENS + tok] = p;
-        }
-        if (io.selected_out) {
-            const float best = wave_max_f32(cand ? p : -1.0f);
-            const unsigned long long m = __ballot(cand && p == best) & 0xFFFFFFFFull;
-            const int btok = __ffsll((long long)m) - 1;
-            if (lane == 0) {
-                int act;
-                if (io.problem == DGL_PROBLEM_TSP || btok < io.k_last)
-                    act = io.idx_last[(size_t)r * io.idx_stride + btok];
-                else
-                    act = io.idx_depot[(size_t)r * io.idx_dep_stride + (btok - io.k_last - 1)] + io.N + 1;
-                io.selected_out[r] = act;
-            }
-        }
+        for (int ww = 0; ww < 4; ++ww) logit += part[(ww * ROWS + rr) * 32 + q];
+        policy_row_output(io, r, logit);
     }
 }
 
@@ -531,10 +458,10 @@ static int launch_policy(const float *P, const dgl_policy_io_t *io, hipStream_t 
     const size_t lds = (size_t)(2 * ROWS * 32 * LDX + 4 * ROWS * 32) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)policy_kernel<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)policy_kernel_f32<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(policy_kernel<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
+    hipLaunchKernelGGL(policy_kernel_f32<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");
     return DGL_OK;
 }
@@ -547,6 +474,8 @@ extern "C" int dgl_policy_forward(const float *packed_weights, const dgl_policy_
                   DGL_TILE_STRIDE);
     // two rows per workgroup share every weight fragment; a single row per workgroup
     // keeps all 256 CUs busy when there are few rows
+    if (io->arithmetic == DGL_ARITH_SPLIT_F16) return dgl_launch_policy16(packed_weights, io, (hipStream_t)stream);
+    DGL_CHECK_ARG(io->arithmetic == DGL_ARITH_F32, "unknown arithmetic %d", io->arithmetic);
     static const int forced = getenv("DGL_POLICY_ROWS") ? atoi(getenv("DGL_POLICY_ROWS")) : 0;
     const int rows = forced ? forced : (io->R >= 512 ? 2 : 1);
     if (rows == 2) return launch_policy<2>(packed_weights, io, (hipStream_t)stream);

@@ -1,0 +1,374 @@
+// Policy network of the DGL decode step on gfx950, dense contractions on the binary16 matrix
+// cores with split operands: encoder block + 3 decoder blocks, d = 128, 8 heads x 16, FF 512,
+// no LayerNorm (TSP/TSPModel.py:238-457, CVRP/CVRPModel.py:378-642).
+//
+// Arithmetic: every weight x activation product is evaluated as
+//     (Wh + Wl)(Xh + Xl) ~= Wl*Xh + Wh*Xl + Wh*Xh,   h = binary16(v), l = binary16(v - h),
+// three v_mfma_f32_32x32x16_f16 with binary32 accumulation.  Each operand keeps 22 significant
+// bits and the products are exact in the accumulator, so the result is as close to the real dot
+// product as a binary32 FMA chain (tools/check_mfma16.hip measures both), at 16/3 of the f32
+// matrix rate.  Weights are split once by dgl_policy_pack, activations when they are written to
+// LDS.  The 32x32 attention products (4 % of the work) run on the f32-input instruction straight
+// from the accumulators; softmax, residuals, biases and the output stage are binary32 VALU.
+//
+// Execution shape
+//   * one workgroup = 4 waves handles ROWS rows (partial tours); a row is one 32-token tile;
+//   * wave w owns output features [32w, 32w+32) of every 128-wide projection, i.e. heads 2w and
+//     2w+1: Q, K, V and the attention of those heads never leave its registers, and neither does
+//     its slice of the residual stream (lane = token, registers = features);
+//   * what the other waves need of an activation is its split image in LDS: XH/XL[token][feature]
+//     binary16, row stride 136 halfs, so the 16-byte operand read of a lane (8 consecutive k of
+//     one token) is bank-conflict free;
+//   * weights stream from L2 in consumption order through a 16-deep register ring per wave.
+//
+// Operand roles: for D[32x32] += A[32x16] * B[16x32] lane l supplies A[l&31][8(l>>5)+j] and
+// B[8(l>>5)+j][l&31], j = 0..7; register r of lane l is D[(r&3)+8(r>>2)+4(l>>5)][l&31].  A lane
+// (q, h) therefore always fetches X[token q][16s+8h..] and W[out q][16s+8h..]; passing (W, X)
+// gives Y^T (lane = token, registers = features), passing (X, W) gives Y (lane = feature,
+// registers = tokens).
+#include <cstdlib>
+
+#include "policy_layout.h"
+
+#define LDH 136                               // LDS row stride in halfs
+#define ARR (32 * LDH)                        // halfs per [32 tokens][128 features] image
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
+// of this lane's half): dst points at [token][feature base + 4h]
+__device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float16 *L) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = x[4 * g + e];
+            hi[e] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        *reinterpret_cast<f16x4 *>(H + 8 * g) = hi;
+        *reinterpret_cast<f16x4 *>(L + 8 * g) = lo;
+    }
+}
+
+// acc[rr] += W(out tile) * X[rr]^T over K = 128 (8 steps of 16): transposed product, lane = token.
+// H, L: this lane's operand pointer into the hi / lo image of row 0 ([token q][8h]); rows ARRS apart.
+template <int ROWS, int ARRS>
+__device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
+                                         f32x16 (&acc)[ROWS]) {
+    // activation operands are read one K-step ahead of the MFMAs that consume them
+    f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS);
+        nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS);
+    }
+    Unroll<0, 8>::run([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        const f16x8 wh = as_h8(ring.template take<(2 * s) % PF16>());
+        const f16x8 wl = as_h8(ring.template take<(2 * s + 1) % PF16>());
+        f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+        if constexpr (s + 1 < 8) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS + 16 * (s + 1));
+                nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS + 16 * (s + 1));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads ahead of this step's MFMAs
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+            acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
+            acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+        }
+    });
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
+    extern __shared__ float lds[];
+    constexpr int ROWH = 6 * ARR;                                   // halfs per row: XH XL BH BL CH CL
+    _Float16 *base = reinterpret_cast<_Float16 *>(lds);
+    float *part = lds + ROWS * ROWH / 2;                            // [4][ROWS][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * ROWS;
+    const int n = io.n;
+    // image pointers of row 0 (rows ROWH apart)
+    _Float16 *XH = base, *XL = base + ARR, *BH = base + 2 * ARR, *BL = base + 3 * ARR, *CH = base + 4 * ARR,
+             *CL = base + 5 * ARR;
+    const int rd = q * LDH + 8 * h;                // operand read offset: [token q][8h]
+    const int wr = q * LDH + 32 * w + 4 * h;       // split store offset: [token q][32w + 4h]
+
+    WeightRing<PF16> ring;
+    ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM16 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
+
+    // ---- embedding, directly in the residual layout: xres[rr][r] = X[token q][feature f(r)],
+    //      f(r) = 32w + (r&3) + 8(r>>2) + 4h;  X = b + sum_f tile[token][f] * We[c][f]
+    f32x16 xres[ROWS];
+    {
+        f32x4 t[ROWS][3];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int r = row0 + rr;
+            const bool live = r < io.R && q < n;
+            const f32x4 *tp = reinterpret_cast<const f32x4 *>(io.tile + (size_t)(live ? r : 0) * io.tile_row_stride +
+                                                             (live ? q : 0) * DGL_TILE_STRIDE);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                t[rr][i] = tp[i];
+                if (!live) t[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(P + PK_EMB_W + c * EMB_IN);
+            const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float be = P[PK_EMB_B + c];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][0][f], w0[f], acc);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][1][f], w1[f], acc);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][2][f], w2[f], acc);
+                const bool live = (row0 + rr) < io.R && q < n;
+                xres[rr][r] = live ? acc + be : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+    }
+    __syncthreads();
+
+    const int anchor0 = io.k_last, anchor1 = n - 1;    // TSP: k_last == n-1
+
+    for (int layer = 0; layer < 4; ++layer) {
+        const float *PV = P + PK_VEC0 + layer * PKV_SIZE;
+
+        if (layer == 1) {
+            // decoder entry: re-embed the anchor token(s) (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-446)
+            // (the stream always carries two embeddings; TSP's second equals its first and is discarded)
+            f32x16 a0[ROWS], a1[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) { a0[rr] = zero16(); a1[rr] = zero16(); }
+            gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, a0);
+            gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, a1);
+            __syncthreads();                           // every wave has finished reading X
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int tok = (a == 0) ? anchor0 : anchor1;
+                if (q == tok && (a == 0 || io.problem == DGL_PROBLEM_CVRP)) {
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int f = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            xres[rr][r] = (a == 0 ? a0[rr][r] : a1[rr][r]) + P[PK_ANCHOR_B + a * D_MODEL + f];
+                        }
+                        store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- Q^T, K^T (transposed form) and V (normal form) for heads 2w, 2w+1 ----
+        f32x16 aq[ROWS], ak[ROWS], av[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { aq[rr] = zero16(); ak[rr] = zero16(); av[rr] = zero16(); }
+        {
+            f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(XH + rr * ROWH + rd);
+                nl[rr] = *reinterpret_cast<const f16x8 *>(XL + rr * ROWH + rd);
+            }
+            Unroll<0, 8>::run([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                const f16x8 qh = as_h8(ring.template take<(6 * s) % PF16>());
+                const f16x8 ql = as_h8(ring.template take<(6 * s + 1) % PF16>());
+                const f16x8 kh = as_h8(ring.template take<(6 * s + 2) % PF16>());
+                const f16x8 kl = as_h8(ring.template take<(6 * s + 3) % PF16>());
+                const f16x8 vh = as_h8(ring.template take<(6 * s + 4) % PF16>());
+                const f16x8 vl = as_h8(ring.template take<(6 * s + 5) % PF16>());
+                f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+                if constexpr (s + 1 < 8) {
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+                        nh[rr] = *reinterpret_cast<const f16x8 *>(XH + rr * ROWH + rd + 16 * (s + 1));
+                        nl[rr] = *reinterpret_cast<const f16x8 *>(XL + rr * ROWH + rd + 16 * (s + 1));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    aq[rr] = MFMA16(ql, xh[rr], aq[rr]);
+                    aq[rr] = MFMA16(qh, xl[rr], aq[rr]);
+                    aq[rr] = MFMA16(qh, xh[rr], aq[rr]);
+                    ak[rr] = MFMA16(kl, xh[rr], ak[rr]);
+                    ak[rr] = MFMA16(kh, xl[rr], ak[rr]);
+                    ak[rr] = MFMA16(kh, xh[rr], ak[rr]);
+                    av[rr] = MFMA16(xh[rr], vl, av[rr]);
+                    av[rr] = MFMA16(xl[rr], vh, av[rr]);
+                    av[rr] = MFMA16(xh[rr], vh, av[rr]);
+                }
+            });
+        }
+
+        // ---- attention, both local heads, straight from the accumulators (f32-input MFMA) ----
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            f32x16 o_sel = zero16();
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                // S^T[key j][query i] = sum_d K[j][d] Q[i][d]
+                f32x16 s = zero16();
+#pragma unroll
+                for (int m = 0; m < 8; ++m) s = MFMA32(ak[rr][8 * hd + m], aq[rr][8 * hd + m], s);
+                // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
+                // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
+                //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
+                float mx = -INFINITY;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int j = (m & 3) + 8 * (m >> 2) + 4 * h;
+                    s[m] = (j < n) ? s[m] : -INFINITY;
+                    mx = fmaxf(mx, s[m]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    s[m] = __builtin_amdgcn_exp2f((s[m] - mx) * 0.36067376022224085f);
+                    sum += s[m];
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) s[m] = s[m] * inv;
+                // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7
+                f32x16 o = zero16();
+#pragma unroll
+                for (int m = 0; m < 16; ++m) o = MFMA32(av[rr][m], s[m], o);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m];
+            }
+            store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr);
+        }
+        __syncthreads();
+
+        // ---- multi_head_combine + residual -> o1 -------------------------------------
+        {
+            f32x16 acc[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
+            gemm16_t<ROWS, ROWH>(ring, BH + rd, BL + rd, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bb = PV[PKV_BC + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (acc[rr][r] + bb);
+            }
+            // every wave passed the barrier above after its Q/K/V reads of X: X may be replaced
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+        }
+        __syncthreads();
+
+        // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
+        {
+            f32x16 af[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) af[rr] = zero16();
+#pragma unroll
+            for (int hc = 0; hc < 4; ++hc) {
+                _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
+                f32x16 ah[ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
+                gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, ah);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bb = PV[PKV_B1 + 128 * hc + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) ah[rr][r] = fmaxf(ah[rr][r] + bb, 0.0f);
+                }
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr);
+                __syncthreads();
+                gemm16_t<ROWS, ROWH>(ring, HH + rd, HL + rd, af);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bb = PV[PKV_B2 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (af[rr][r] + bb);
+            }
+            // the last barrier came after every wave's last read of X (W1 of chunk 3)
+            if (layer < 3) {
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- Linear_final: logit[token] = bf + sum_c X[token][c] wf[c] ---------------------
+    {
+        float wf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wf[r] = P[PK_FINAL_W + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = fmaf(xres[rr][r], wf[r], acc);
+            acc += __shfl_xor(acc, 32, 64);
+            if (h == 0) part[(w * ROWS + rr) * 32 + q] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- masked softmax, floor, greedy pick: wave w handles rows w, w+4, ... ------------
+    for (int rr = w; rr < ROWS; rr += 4) {
+        const int r = row0 + rr;
+        if (r >= io.R) continue;
+        float logit = P[PK_FINAL_B];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) logit += part[(ww * ROWS + rr) * 32 + q];
+        policy_row_output(io, r, logit);
+    }
+}
+
+template <int ROWS>
+static int launch16(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
+    const size_t lds = (size_t)ROWS * 6 * ARR * sizeof(_Float16) + (size_t)4 * ROWS * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)policy_kernel_f16<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(policy_kernel_f16<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
+    DGL_CHECK_LAUNCH("dgl_policy_forward");
+    return DGL_OK;
+}
+
+int dgl_launch_policy16(const float *packed, const dgl_policy_io_t *io, hipStream_t stream) {
+    // two rows per workgroup share every weight fragment; a single row per workgroup keeps all
+    // 256 CUs busy when there are few rows
+    static const int forced = getenv("DGL_POLICY_ROWS") ? atoi(getenv("DGL_POLICY_ROWS")) : 0;
+    const int rows = forced ? forced : (io->R >= 512 ? 2 : 1);
+    if (rows == 2) return launch16<2>(packed, io, stream);
+    return launch16<1>(packed, io, stream);
+}

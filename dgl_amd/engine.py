@@ -7,6 +7,7 @@ classes (dgl_amd.tsp / dgl_amd.cvrp / dgl_amd.beamsearch) sit on top of these.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -15,6 +16,17 @@ from . import _lib
 from ._lib import PROBLEM_CVRP, PROBLEM_TSP, MAX_TOKENS, TILE_STRIDE, check, ptr, stream_ptr
 
 _BLOCKS = ["encoder.layers.0.", "decoder.layers.0.", "decoder.layers.1.", "decoder.layers.2."]
+
+
+def default_arithmetic() -> int:
+    """Arithmetic of the dense contractions (include/dgl_amd.h, DGL_ARITH_*): the f16 split-operand
+    matrix cores unless DGL_ARITHMETIC=f32 asks for the f32-input matrix instructions."""
+    name = os.environ.get("DGL_ARITHMETIC", "split_f16").lower()
+    if name in ("f32", "fp32"):
+        return _lib.ARITH_F32
+    if name in ("split_f16", "f16x3"):
+        return _lib.ARITH_SPLIT_F16
+    raise ValueError(f"DGL_ARITHMETIC={name!r}: expected 'split_f16' or 'f32'")
 
 
 class PackedPolicy:
@@ -60,6 +72,7 @@ class TspEngine:
     def __init__(self, xy: torch.Tensor, rows_per_instance: int, knn: int):
         assert xy.is_cuda and xy.dtype == torch.float32 and xy.dim() == 3 and xy.shape[2] == 2
         self.lib = _lib.load()
+        self.arithmetic = default_arithmetic()
         self.xy = xy.contiguous()
         self.B, self.N = xy.shape[0], xy.shape[1]
         self.rpi = rows_per_instance
@@ -136,7 +149,7 @@ class TspEngine:
     def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
         k = self.k
         return _lib.PolicyIO(PROBLEM_TSP, self.R, k + 1, k, self.N, self.knn, 0, (self.knn + 1) * TILE_STRIDE,
-                             ptr(self.tile), ptr(self.idx), 0, 0,
+                             self.arithmetic, 0, ptr(self.tile), ptr(self.idx), 0, 0,
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)
 
@@ -217,6 +230,7 @@ class CvrpEngine:
         assert xy.is_cuda and xy.dtype == torch.float32 and xy.dim() == 3 and xy.shape[2] == 2
         assert demand.is_cuda and demand.dtype == torch.float32 and demand.shape == xy.shape[:2]
         self.lib = _lib.load()
+        self.arithmetic = default_arithmetic()
         self.xy, self.demand = xy.contiguous(), demand.contiguous()
         self.B, self.M = xy.shape[0], xy.shape[1]
         self.N = self.M - 1
@@ -307,7 +321,7 @@ class CvrpEngine:
     def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
         kl, kd = self.kl, self.kd
         return _lib.PolicyIO(PROBLEM_CVRP, self.R, kl + kd + 2, kl, self.N, self.knn, self.depot_knn,
-                             self.ntok_max * TILE_STRIDE, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
+                             self.ntok_max * TILE_STRIDE, self.arithmetic, 0, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
                              ptr(self.infeasible),
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)

@@ -191,6 +191,15 @@ DGL_API int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl_st
  *  prob_out [R][DGL_MAX_TOKENS] = floored softmax probability per token (anchors 0),
  *  selected_out [R] = greedy action: TSP node id; CVRP action id (node, or node+N+1 via
  *  depot); ties -> lowest action id. */
+/* Arithmetic of the weight x activation contractions (everything else is binary32 either way):
+ *  DGL_ARITH_SPLIT_F16: every operand is split into hi = binary16(x), lo = binary16(x - hi) and the
+ *    product is evaluated as hi*hi + hi*lo + lo*hi on the binary16 matrix cores with binary32
+ *    accumulation (22 significant bits per operand; measured error no larger than a binary32 FMA
+ *    chain of the same length).  Operands beyond +-65504 saturate.
+ *  DGL_ARITH_F32: binary32-input matrix instructions, bitwise equal to FMA chains. */
+#define DGL_ARITH_SPLIT_F16 0
+#define DGL_ARITH_F32 1
+
 typedef struct {
     int32_t problem;
     int32_t R;
@@ -200,6 +209,8 @@ typedef struct {
     int32_t idx_stride;   /* row stride of idx_last / infeasible */
     int32_t idx_dep_stride;
     int32_t tile_row_stride; /* floats between consecutive rows of `tile` (>= n*DGL_TILE_STRIDE) */
+    int32_t arithmetic;   /* DGL_ARITH_* : how the dense contractions are evaluated */
+    int32_t reserved;     /* 0 */
     const float *tile;
     const int32_t *idx_last;    /* [R][idx_stride] */
     const int32_t *idx_depot;   /* [R][idx_dep_stride] (CVRP) */

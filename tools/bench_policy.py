@@ -1,6 +1,6 @@
 """Micro-benchmark of dgl_policy_forward alone (for profiling): R rows of random tiles."""
-import sys, time, torch
-sys.path.insert(0, '.')
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from dgl_amd._lib import PROBLEM_TSP
 from dgl_amd.engine import PackedPolicy, TspEngine
 from dgl_amd.weights import random_state_dict
