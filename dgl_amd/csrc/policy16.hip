@@ -19,7 +19,9 @@
 //   * what the other waves need of an activation is its split image in LDS: XH/XL[token][feature]
 //     binary16, row stride 136 halfs, so the 16-byte operand read of a lane (8 consecutive k of
 //     one token) is bank-conflict free;
-//   * weights stream from L2 in consumption order through a 16-deep register ring per wave.
+//   * weights stream from L2 in consumption order through a 32-deep register ring per wave
+//     (32 KB in flight); nothing else uses vector loads inside the layer loop, so no wait on a
+//     small load ever drains the ring.
 //
 // Operand roles: for D[32x32] += A[32x16] * B[16x32] lane l supplies A[l&31][8(l>>5)+j] and
 // B[8(l>>5)+j][l&31], j = 0..7; register r of lane l is D[(r&3)+8(r>>2)+4(l>>5)][l&31].  A lane
@@ -36,6 +38,13 @@
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// Element of a 32-float vector slice (wave-uniform pointer v) that belongs to register r of a lane
+// in half-wave h: both candidates arrive through scalar loads, the lane picks its own.
+__device__ __forceinline__ float slice_at(const float *v, int r, int h) {
+    const float b0 = v[(r & 3) + 8 * (r >> 2)], b1 = v[(r & 3) + 8 * (r >> 2) + 4];
+    return h ? b1 : b0;
+}
 
 // hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
 // of this lane's half): dst points at [token][feature base + 4h]
@@ -56,7 +65,8 @@ __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float
 
 // acc[rr] += W(out tile) * X[rr]^T over K = 128 (8 steps of 16): transposed product, lane = token.
 // H, L: this lane's operand pointer into the hi / lo image of row 0 ([token q][8h]); rows ARRS apart.
-template <int ROWS, int ARRS>
+// BASE: position of the GEMM's first fragment in the wave's stream, modulo the ring depth.
+template <int ROWS, int ARRS, int BASE>
 __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                          f32x16 (&acc)[ROWS]) {
     // activation operands are read one K-step ahead of the MFMAs that consume them
@@ -68,8 +78,8 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
     }
     Unroll<0, 8>::run([&](auto ss) {
         constexpr int s = decltype(ss)::value;
-        const f16x8 wh = as_h8(ring.template take<(2 * s) % PF16>());
-        const f16x8 wl = as_h8(ring.template take<(2 * s + 1) % PF16>());
+        const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
+        const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
         f16x8 xh[ROWS], xl[ROWS];
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
@@ -102,6 +112,7 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
     // image pointers of row 0 (rows ROWH apart)
     _Float16 *XH = base, *XL = base + ARR, *BH = base + 2 * ARR, *BL = base + 3 * ARR, *CH = base + 4 * ARR,
              *CL = base + 5 * ARR;
+    const int ws = __builtin_amdgcn_readfirstlane(w);      // wave-uniform: bias vectors come through scalar loads
     const int rd = q * LDH + 8 * h;                // operand read offset: [token q][8h]
     const int wr = q * LDH + 32 * w + 4 * h;       // split store offset: [token q][32w + 4h]
 
@@ -160,8 +171,8 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
             f32x16 a0[ROWS], a1[ROWS];
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) { a0[rr] = zero16(); a1[rr] = zero16(); }
-            gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, a0);
-            gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, a1);
+            gemm16_t<ROWS, ROWH, 0>(ring, XH + rd, XL + rd, a0);
+            gemm16_t<ROWS, ROWH, 16>(ring, XH + rd, XL + rd, a1);
             __syncthreads();                           // every wave has finished reading X
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -170,10 +181,9 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int f = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            xres[rr][r] = (a == 0 ? a0[rr][r] : a1[rr][r]) + P[PK_ANCHOR_B + a * D_MODEL + f];
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            xres[rr][r] = (a == 0 ? a0[rr][r] : a1[rr][r]) +
+                                          slice_at(P + PK_ANCHOR_B + a * D_MODEL + 32 * ws, r, h);
                         store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
                     }
                 }
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
             f32x16 acc[ROWS];
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
-            gemm16_t<ROWS, ROWH>(ring, BH + rd, BL + rd, acc);
+            gemm16_t<ROWS, ROWH, 48>(ring, BH + rd, BL + rd, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float bb = PV[PKV_BC + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+                const float bb = slice_at(PV + PKV_BC + 32 * ws, r, h);
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (acc[rr][r] + bb);
             }
@@ -291,27 +301,27 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
             f32x16 af[ROWS];
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) af[rr] = zero16();
-#pragma unroll
-            for (int hc = 0; hc < 4; ++hc) {
+            Unroll<0, 4>::run([&](auto hcc) {
+                constexpr int hc = decltype(hcc)::value;
                 _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
                 f32x16 ah[ROWS];
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
-                gemm16_t<ROWS, ROWH>(ring, XH + rd, XL + rd, ah);
+                gemm16_t<ROWS, ROWH, 64 + 32 * hc>(ring, XH + rd, XL + rd, ah);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bb = PV[PKV_B1 + 128 * hc + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    const float bb = slice_at(PV + PKV_B1 + 128 * hc + 32 * ws, r, h);
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) ah[rr][r] = fmaxf(ah[rr][r] + bb, 0.0f);
                 }
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr);
                 __syncthreads();
-                gemm16_t<ROWS, ROWH>(ring, HH + rd, HL + rd, af);
-            }
+                gemm16_t<ROWS, ROWH, 80 + 32 * hc>(ring, HH + rd, HL + rd, af);
+            });
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float bb = PV[PKV_B2 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+                const float bb = slice_at(PV + PKV_B2 + 32 * ws, r, h);
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (af[rr][r] + bb);
             }
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
     {
         float wf[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wf[r] = P[PK_FINAL_W + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        for (int r = 0; r < 16; ++r) wf[r] = slice_at(P + PK_FINAL_W + 32 * ws, r, h);
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             float acc = 0.0f;

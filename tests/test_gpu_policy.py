@@ -1,0 +1,96 @@
+"""GPU tests of the policy kernels' two arithmetic modes (include/dgl_amd.h, DGL_ARITH_*): the
+f16 split-operand kernel must agree with the f32-input kernel far inside the 1e-3 logit bound,
+and the f32-input kernel keeps its parity with the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _tsp_engine(R, N, knn, device, seed=0):
+    from dgl_amd.engine import TspEngine
+    g = torch.Generator().manual_seed(seed)
+    eng = TspEngine(torch.rand(R, N, 2, generator=g).to(device), 1, knn)
+    eng.reset()
+    eng.step(torch.randint(0, N, (R,), generator=g, dtype=torch.int32).to(device))
+    return eng
+
+
+@pytest.mark.parametrize("R", [5, 600])          # one row per workgroup / two rows per workgroup (+ ragged tail)
+@pytest.mark.parametrize("weights", ["random", "trained"])
+def test_tsp_split_f16_agrees_with_f32(R, weights, device):
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd.weights import load_checkpoint, random_state_dict
+    import os
+    from conftest import GOLDEN
+    sd = random_state_dict("TSP", 3) if weights == "random" else load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt"))
+    eng = _tsp_engine(R, 300, 30, device)
+    pol = PackedPolicy(sd, _lib.PROBLEM_TSP, device)
+    out = {}
+    for mode in (_lib.ARITH_F32, _lib.ARITH_SPLIT_F16):
+        eng.arithmetic = mode
+        eng.logits.zero_(); eng.prob.zero_(); eng.selected.zero_()
+        eng.forward(pol)
+        torch.cuda.synchronize()
+        out[mode] = (eng.logits[:, :31].cpu().numpy().copy(), eng.prob[:, :31].cpu().numpy().copy(),
+                     eng.selected.cpu().numpy().copy())
+    a, b = out[_lib.ARITH_F32], out[_lib.ARITH_SPLIT_F16]
+    scale = np.abs(a[0]).max(axis=1, keepdims=True)
+    rel = float((np.abs(a[0] - b[0]) / scale).max())
+    print(f"R={R} {weights}: max relative logit difference split-f16 vs f32 kernels {rel:.2e}")
+    assert rel < 2e-5                               # both are f32-accurate evaluations of the same sums
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-4, atol=1e-7)
+    assert (a[2] == b[2]).mean() >= 0.99
+
+
+def test_cvrp_split_f16_agrees_with_f32(device):
+    from dgl_amd import _lib
+    from dgl_amd.engine import CvrpEngine, PackedPolicy
+    from dgl_amd.weights import random_state_dict
+    g = torch.Generator().manual_seed(1)
+    B, N = 520, 200
+    xy = torch.rand(B, N + 1, 2, generator=g)                      # depot first
+    demand = torch.cat([torch.zeros(B, 1), torch.randint(1, 10, (B, N), generator=g).float() / 40.0], 1)
+    eng = CvrpEngine(xy.to(device), demand.to(device), 1, 15, 15)
+    eng.reset()
+    eng.step(torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32).to(device) + N + 1)
+    pol = PackedPolicy(random_state_dict("CVRP", 5), _lib.PROBLEM_CVRP, device)
+    out = {}
+    for mode in (_lib.ARITH_F32, _lib.ARITH_SPLIT_F16):
+        eng.arithmetic = mode
+        eng.forward(pol)
+        torch.cuda.synchronize()
+        out[mode] = (eng.logits[:, :32].cpu().numpy().copy(), eng.selected.cpu().numpy().copy())
+    a, b = out[_lib.ARITH_F32], out[_lib.ARITH_SPLIT_F16]
+    rel = float((np.abs(a[0] - b[0]) / np.abs(a[0]).max(axis=1, keepdims=True)).max())
+    print(f"CVRP: max relative logit difference split-f16 vs f32 kernels {rel:.2e}")
+    assert rel < 2e-5
+    assert (a[1] == b[1]).mean() >= 0.99
+
+
+@pytest.mark.parametrize("name", ["tsp_n100_b8", "tsp_n100_b64_nn"])
+def test_f32_kernel_logits_match_golden(name, device):
+    """The f32-input kernel (selectable, not the default) against the reference's logits."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    case, weights = load_golden(name)
+    eng = TspEngine(torch.from_numpy(case["xy"]).to(device), 1, int(case["meta/knn"]))
+    eng.arithmetic = _lib.ARITH_F32
+    pol = PackedPolicy(weights, _lib.PROBLEM_TSP, device)
+    tour = torch.from_numpy(case["tour"]).to(device=device, dtype=torch.int32)
+    eng.reset()
+    worst = 0.0
+    for t in range(1, eng.N):
+        eng.step(tour[:, t - 1].contiguous())
+        k = eng.k
+        ok = (eng.idx.cpu().numpy()[:, :k] == case["idx"][t - 1][:, :k]).all(axis=1)
+        eng.forward(pol)
+        lg, g = eng.logits.cpu().numpy()[:, :k + 1], case["logits"][t - 1][:, :k + 1]
+        if ok.any():
+            worst = max(worst, float((np.abs(lg[ok] - g[ok]) / np.abs(g[ok]).max(axis=1, keepdims=True)).max()))
+    print(f"{name}: f32 kernel max relative logit error {worst:.2e}")
+    assert worst < 1e-3
