@@ -12,8 +12,10 @@ k = 30 (BASELINE.json configs[1]); ``--problem cvrp`` runs CVRP-1000 (configs[2]
 Rank 0 prints ONE JSON line.  ``value`` is whole-job instances/s (all ranks; instances are
 independent, so ranks shard them with no data-path collective: weak scaling); only the
 tour-length statistics are all-reduced (RCCL) at the end.  ``roofline`` describes the
-dominant kernel (the fp32-MFMA policy network), timed with HIP events on the launch stream
-inside the timed region; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
+dominant kernel (the policy network; its dense contractions run on the f16 matrix cores with
+split operands, three f16 products per f32-accurate product, so the peak it is priced against is
+the dense f16 peak / 3), timed with HIP events on the launch stream inside the timed region;
+``policy_f32_kernel`` times the selectable f32-input-MFMA kernel on the same tiles; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
 the workload's batch and at a batch large enough to fill the chip.  ``cpu_baseline`` is the
 oracle (the PyTorch-CPU restatement of the reference path) on a bounded sample.
 """
@@ -31,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X dense fp32 MFMA (v_mfma_f32_32x32x2_f32), spec
+PEAK_F16_MATRIX_TFLOPS = 2516.8   # MI355X dense f16/bf16 MFMA (16 x the f32-input rate), spec
+SPLIT_PASSES = 3                  # f16 products per f32-accurate product (hi*hi + hi*lo + lo*hi)
 PEAK_HBM_GBS = 8000.0             # MI355X HBM3E, spec
 
 
@@ -79,7 +83,7 @@ def main():
 
     from dgl_amd import build
     build.build()                                   # no-op when the in-tree library is current
-    from dgl_amd._lib import PROBLEM_CVRP, PROBLEM_TSP
+    from dgl_amd._lib import ARITH_F32, ARITH_SPLIT_F16, PROBLEM_CVRP, PROBLEM_TSP
     from dgl_amd.engine import CvrpEngine, PackedPolicy, TspEngine
     from dgl_amd.weights import random_state_dict
 
@@ -155,6 +159,8 @@ def main():
         ms_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
         ms_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
         flops = policy_flops_per_row(n_tok, feat, anchors) * B
+        split = eng.arithmetic == ARITH_SPLIT_F16
+        peak_tf = PEAK_F16_MATRIX_TFLOPS / SPLIT_PASSES if split else PEAK_FP32_MATRIX_TFLOPS
         ach_tf = flops / (ms_policy * 1e-3) / 1e12 if ms_policy > 0 else 0.0
         bytes_knn = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * B
         ach_gbs = bytes_knn / (ms_knn * 1e-3) / 1e9 if ms_knn > 0 else 0.0
@@ -165,23 +171,41 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (f16 split-operand MFMA x3, f32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.problem.upper()}-{N} greedy decode, {B} uniform instances per GPU, "
                                    f"k={knn}" + (f"/{knn}" if cvrp else "") + ", random-init weights",
                        "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}"},
             "decode_steps_per_s": args.steps * decisions / elapsed,
             "row_decisions_per_s": world * B * args.steps * decisions / elapsed,
             "mean_tour_length": mean_len,
-            "roofline": {"kernel": "policy_kernel", "bound": "mfma", "achieved": ach_tf,
-                         "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / PEAK_FP32_MATRIX_TFLOPS,
+            "roofline": {"kernel": "policy_kernel_f16" if split else "policy_kernel_f32", "bound": "mfma",
+                         "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
                          "traffic": None, "avg_launch_ms": ms_policy, "flops_per_launch": flops,
-                         "samples": len(ev_policy)},
+                         "samples": len(ev_policy),
+                         "peak_note": (f"dense f16 MFMA peak {PEAK_F16_MATRIX_TFLOPS} / {SPLIT_PASSES} passes per "
+                                       "f32-accurate product" if split else "dense f32-input MFMA peak"),
+                         "frac_of_f16_dense_peak": ach_tf / PEAK_F16_MATRIX_TFLOPS},
             "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
                              "avg_launch_ms": ms_knn, "bytes_per_launch": bytes_knn, "rows": B},
         }
         if not args.no_aux and world == 1:
             out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, args.problem, N, knn)
+            if split:                                # the f32-input kernel on tiles of the same shape, outside the timed region
+                eng.reset(); eng.step(start)
+                eng.arithmetic = ARITH_F32
+                for _ in range(3):
+                    eng.forward(policy, want_logits=False, want_prob=False)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(10):
+                    eng.forward(policy, want_logits=False, want_prob=False)
+                b.record(); torch.cuda.synchronize()
+                eng.arithmetic = ARITH_SPLIT_F16
+                ms32 = a.elapsed_time(b) / 10
+                out["policy_f32_kernel"] = {"kernel": "policy_kernel_f32", "avg_launch_ms": ms32,
+                                            "achieved": flops / (ms32 * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.problem, N, knn, args.cpu_sample)
         print(json.dumps(out), flush=True)

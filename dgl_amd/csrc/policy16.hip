@@ -8,8 +8,8 @@
 // bits and the products are exact in the accumulator, so the result is as close to the real dot
 // product as a binary32 FMA chain (tools/check_mfma16.hip measures both), at 16/3 of the f32
 // matrix rate.  Weights are split once by dgl_policy_pack, activations when they are written to
-// LDS.  The 32x32 attention products (4 % of the work) run on the f32-input instruction straight
-// from the accumulators; softmax, residuals, biases and the output stage are binary32 VALU.
+// LDS, Q/K/V and the attention probabilities in registers.  Softmax, residuals, biases and the
+// output stage are binary32 VALU.
 //
 // Execution shape
 //   * one workgroup = 4 waves handles ROWS rows (partial tours); a row is one 32-token tile;
@@ -19,9 +19,9 @@
 //   * what the other waves need of an activation is its split image in LDS: XH/XL[token][feature]
 //     binary16, row stride 136 halfs, so the 16-byte operand read of a lane (8 consecutive k of
 //     one token) is bank-conflict free;
-//   * weights stream from L2 in consumption order through a 32-deep register ring per wave
-//     (32 KB in flight); nothing else uses vector loads inside the layer loop, so no wait on a
-//     small load ever drains the ring.
+//   * weights stream from L2 in consumption order through a register ring per wave; bias vectors
+//     are staged in LDS once, so nothing else uses vector loads inside the layer loop and no wait
+//     on a small load ever drains the ring.
 //
 // Operand roles: for D[32x32] += A[32x16] * B[16x32] lane l supplies A[l&31][8(l>>5)+j] and
 // B[8(l>>5)+j][l&31], j = 0..7; register r of lane l is D[(r&3)+8(r>>2)+4(l>>5)][l&31].  A lane
@@ -39,11 +39,35 @@
 
 __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-// Element of a 32-float vector slice (wave-uniform pointer v) that belongs to register r of a lane
-// in half-wave h: both candidates arrive through scalar loads, the lane picks its own.
-__device__ __forceinline__ float slice_at(const float *v, int r, int h) {
-    const float b0 = v[(r & 3) + 8 * (r >> 2)], b1 = v[(r & 3) + 8 * (r >> 2) + 4];
-    return h ? b1 : b0;
+#define NVEC (PK_STREAM0 - PK_VEC0)              // bias vectors + final weights, staged in LDS
+
+// Split of activations: hi = v with its significand truncated to 11 bits (exactly representable
+// in binary16 for |v| in [2^-14, 65520)), lo = v - hi (exact), both converted with the packed
+// round-towards-zero instruction: three VALU operations per value, 22 significant bits kept.
+// Larger magnitudes saturate at the largest finite binary16, smaller ones keep an absolute
+// accuracy of 2^-24.
+__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u), bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
+    hi = pack_rtz(ah, bh);
+    lo = pack_rtz(a - ah, b - bh);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// registers r0..r0+7 of an accumulator tile as one MFMA operand fragment (hi and lo)
+__device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8 &lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned a, b;
+        split2(x[r0 + 2 * p], x[r0 + 2 * p + 1], a, b);
+        h[p] = a;
+        l[p] = b;
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 
 // hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
@@ -51,15 +75,16 @@ __device__ __forceinline__ float slice_at(const float *v, int r, int h) {
 __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float16 *L) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f16x4 hi, lo;
+        u32x2 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = x[4 * g + e];
-            hi[e] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
-            lo[e] = (_Float16)(v - (float)hi[e]);
+        for (int p = 0; p < 2; ++p) {
+            unsigned a, b;
+            split2(x[4 * g + 2 * p], x[4 * g + 2 * p + 1], a, b);
+            hi[p] = a;
+            lo[p] = b;
         }
-        *reinterpret_cast<f16x4 *>(H + 8 * g) = hi;
-        *reinterpret_cast<f16x4 *>(L + 8 * g) = lo;
+        *reinterpret_cast<u32x2 *>(H + 8 * g) = hi;
+        *reinterpret_cast<u32x2 *>(L + 8 * g) = lo;
     }
 }
 
@@ -100,22 +125,37 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
     });
 }
 
+#ifdef PROFILE_STAMPS
+#define STAMP() do { if (tid == 0 && nst < 32) st_[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+
 template <int ROWS>
 __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
     extern __shared__ float lds[];
     constexpr int ROWH = 6 * ARR;                                   // halfs per row: XH XL BH BL CH CL
     _Float16 *base = reinterpret_cast<_Float16 *>(lds);
     float *part = lds + ROWS * ROWH / 2;                            // [4][ROWS][32]
+    float *vecs = part + 4 * ROWS * 32;                             // [NVEC] copy of P[PK_VEC0 ..)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * ROWS;
     const int n = io.n;
     // image pointers of row 0 (rows ROWH apart)
     _Float16 *XH = base, *XL = base + ARR, *BH = base + 2 * ARR, *BL = base + 3 * ARR, *CH = base + 4 * ARR,
              *CL = base + 5 * ARR;
-    const int ws = __builtin_amdgcn_readfirstlane(w);      // wave-uniform: bias vectors come through scalar loads
+    // this lane's view of a 128-float vector: registers 4g..4g+3 <-> vl[off + 8g .. 8g+3]
+    const float *vl = vecs + 32 * w + 4 * h;
+    auto vec4 = [&](int off, int g) { return *reinterpret_cast<const f32x4 *>(vl + off + 8 * g); };
     const int rd = q * LDH + 8 * h;                // operand read offset: [token q][8h]
     const int wr = q * LDH + 32 * w + 4 * h;       // split store offset: [token q][32w + 4h]
 
+#ifdef PROFILE_STAMPS
+    unsigned long long st_[32];
+    int nst = 0;
+#endif
+    STAMP();
+    for (int i = tid; i < NVEC; i += 256) vecs[i] = P[PK_VEC0 + i];
     WeightRing<PF16> ring;
     ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM16 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
 
@@ -159,11 +199,12 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
         for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
     }
     __syncthreads();
+    STAMP();
 
     const int anchor0 = io.k_last, anchor1 = n - 1;    // TSP: k_last == n-1
 
     for (int layer = 0; layer < 4; ++layer) {
-        const float *PV = P + PK_VEC0 + layer * PKV_SIZE;
+        const int PV = layer * PKV_SIZE;                 // offset of this block's bias vectors in vecs
 
         if (layer == 1) {
             // decoder entry: re-embed the anchor token(s) (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-446)
@@ -181,9 +222,12 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            xres[rr][r] = (a == 0 ? a0[rr][r] : a1[rr][r]) +
-                                          slice_at(P + PK_ANCHOR_B + a * D_MODEL + 32 * ws, r, h);
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bb = vec4(PK_ANCHOR_B - PK_VEC0 + a * D_MODEL, g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                xres[rr][4 * g + e] = (a == 0 ? a0[rr][4 * g + e] : a1[rr][4 * g + e]) + bb[e];
+                        }
                         store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
                     }
                 }
@@ -236,16 +280,27 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
             });
         }
 
-        // ---- attention, both local heads, straight from the accumulators (f32-input MFMA) ----
+        STAMP();   // QKV done
+        // ---- attention, both local heads, straight from the accumulators --------------------
+        // Accumulator registers serve as split f16 operands without any lane movement: registers
+        // 8t..8t+7 of a tile whose summed index runs over its rows are one K = 16 fragment, with the
+        // same (permuted) k order in both operands.
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             f32x16 o_sel = zero16();
+            f16x8 vh[2], vl[2];                              // V[key][feature]: keys summed, two K-steps
+            split8(av[rr], 0, vh[0], vl[0]);
+            split8(av[rr], 8, vh[1], vl[1]);
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
-                // S^T[key j][query i] = sum_d K[j][d] Q[i][d]
+                // S^T[key j][query i] = sum_d K[j][d] Q[i][d]: the 16 d of this head are one K-step
+                f16x8 kh, kl, qh, ql;
+                split8(ak[rr], 8 * hd, kh, kl);
+                split8(aq[rr], 8 * hd, qh, ql);
                 f32x16 s = zero16();
-#pragma unroll
-                for (int m = 0; m < 8; ++m) s = MFMA32(ak[rr][8 * hd + m], aq[rr][8 * hd + m], s);
+                s = MFMA16(kl, qh, s);
+                s = MFMA16(kh, ql, s);
+                s = MFMA16(kh, qh, s);
                 // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
                 // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
                 //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
@@ -270,13 +325,21 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7
                 f32x16 o = zero16();
 #pragma unroll
-                for (int m = 0; m < 16; ++m) o = MFMA32(av[rr][m], s[m], o);
+                for (int t = 0; t < 2; ++t) {
+                    f16x8 ph, pl;
+                    split8(s, 8 * t, ph, pl);
+                    o = MFMA16(vl[t], ph, o);
+                    o = MFMA16(vh[t], pl, o);
+                    o = MFMA16(vh[t], ph, o);
+                }
 #pragma unroll
                 for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m];
             }
             store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr);
         }
+        STAMP();   // attention done
         __syncthreads();
+        STAMP();   // barrier
 
         // ---- multi_head_combine + residual -> o1 -------------------------------------
         {
@@ -285,16 +348,20 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
             for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
             gemm16_t<ROWS, ROWH, 48>(ring, BH + rd, BL + rd, acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bb = slice_at(PV + PKV_BC + 32 * ws, r, h);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = vec4(PV + PKV_BC, g);
 #pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (acc[rr][r] + bb);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (acc[rr][4 * g + e] + bb[e]);
             }
             // every wave passed the barrier above after its Q/K/V reads of X: X may be replaced
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
         }
+        STAMP();   // combine done
         __syncthreads();
+        STAMP();   // barrier
 
         // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
         {
@@ -309,10 +376,12 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
                 gemm16_t<ROWS, ROWH, 64 + 32 * hc>(ring, XH + rd, XL + rd, ah);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float bb = slice_at(PV + PKV_B1 + 128 * hc + 32 * ws, r, h);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = vec4(PV + PKV_B1 + 128 * hc, g);
 #pragma unroll
-                    for (int rr = 0; rr < ROWS; ++rr) ah[rr][r] = fmaxf(ah[rr][r] + bb, 0.0f);
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) ah[rr][4 * g + e] = fmaxf(ah[rr][4 * g + e] + bb[e], 0.0f);
                 }
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr);
@@ -320,10 +389,12 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 gemm16_t<ROWS, ROWH, 80 + 32 * hc>(ring, HH + rd, HL + rd, af);
             });
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bb = slice_at(PV + PKV_B2 + 32 * ws, r, h);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = vec4(PV + PKV_B2, g);
 #pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) xres[rr][r] = xres[rr][r] + (af[rr][r] + bb);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (af[rr][4 * g + e] + bb[e]);
             }
             // the last barrier came after every wave's last read of X (W1 of chunk 3)
             if (layer < 3) {
@@ -331,14 +402,25 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
             }
         }
+        STAMP();   // FF done
         __syncthreads();
+        STAMP();   // barrier
     }
+#ifdef PROFILE_STAMPS
+    if (tid == 0 && io.logits_out)
+        for (int i = 0; i < 32; ++i) io.logits_out[(size_t)row0 * DGL_MAX_TOKENS + i] = i < nst ? (float)(st_[i] - st_[0]) : 0.f;
+    return;
+#endif
 
     // ---- Linear_final: logit[token] = bf + sum_c X[token][c] wf[c] ---------------------
     {
         float wf[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wf[r] = slice_at(P + PK_FINAL_W + 32 * ws, r, h);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = vec4(PK_FINAL_W - PK_VEC0, g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wf[4 * g + e] = v[e];
+        }
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             float acc = 0.0f;
@@ -363,7 +445,7 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
 
 template <int ROWS>
 static int launch16(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
-    const size_t lds = (size_t)ROWS * 6 * ARR * sizeof(_Float16) + (size_t)4 * ROWS * 32 * sizeof(float);
+    const size_t lds = (size_t)ROWS * 6 * ARR * sizeof(_Float16) + (size_t)(4 * ROWS * 32 + NVEC) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)policy_kernel_f16<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
