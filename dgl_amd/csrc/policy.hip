@@ -114,8 +114,9 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
             for (int hc = 0; hc < 4; ++hc) {
                 tile(k.w1, D_MODEL, 4 * hc + wv, 0, 16, f + 64 + 32 * hc, 1);
                 tile(k.w2, FF_DIM, wv, 16 * hc, 16, f + 64 + 32 * hc + 16, 1);
-                tile16(k.w1, D_MODEL, 4 * hc + wv, 0, 8, f + 64 + 32 * hc, 1);
-                tile16(k.w2, FF_DIM, wv, 8 * hc, 8, f + 64 + 32 * hc + 16, 1);
+                // f16 kernel's software pipeline: W1.0 | W1.1 W2.0 | W1.2 W2.1 | W1.3 W2.2 | W2.3
+                tile16(k.w1, D_MODEL, 4 * hc + wv, 0, 8, f + (hc == 0 ? 64 : 48 + 32 * hc), 1);
+                tile16(k.w2, FF_DIM, wv, 8 * hc, 8, f + (hc == 3 ? 176 : 96 + 32 * hc), 1);
             }
         }
         for (int a = 0; a < 2; ++a) {

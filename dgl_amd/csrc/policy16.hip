@@ -125,6 +125,50 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
     });
 }
 
+// The same GEMM with independent VALU / LDS-store work placed in the shadow of its MFMAs: one wave
+// per SIMD issues in order, an MFMA occupies the issue port for 8 of its 32 cycles, so up to five
+// 4-cycle VALU instructions written between two MFMAs cost nothing.  side(step, row, part) is called
+// after MFMA `part` (0..2) of `row` in K-step `step` and must not depend on acc; scheduling barriers
+// pin the written order.
+template <int ROWS, int ARRS, int BASE, class Side>
+__device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
+                                              f32x16 (&acc)[ROWS], Side side) {
+    f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS);
+        nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS);
+    }
+    Unroll<0, 8>::run([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
+        const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
+        f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+        if constexpr (s + 1 < 8) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS + 16 * (s + 1));
+                nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS + 16 * (s + 1));
+            }
+        }
+        Unroll<0, 3>::run([&](auto pp) {
+            constexpr int part = decltype(pp)::value;
+            Unroll<0, ROWS>::run([&](auto rc) {
+                constexpr int rr = decltype(rc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (part == 0) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+                if constexpr (part == 1) acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
+                if constexpr (part == 2) acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+                __builtin_amdgcn_sched_barrier(0);
+                side(ss, rc, pp);
+            });
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 #ifdef PROFILE_STAMPS
 #define STAMP() do { if (tid == 0 && nst < 32) st_[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -364,17 +408,17 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
         STAMP();   // barrier
 
         // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
+        // Software pipeline: the epilogue of chunk hc (bias, ReLU, split, LDS stores: VALU work) is
+        // interleaved with the MFMAs of the second GEMM of chunk hc-1, which do not depend on it:
+        //   G1(0) E(0) | G1(1) [E(1) || G2(0)] | G1(2) [E(2) || G2(1)] | G1(3) [E(3) || G2(2)] | G2(3)
+        // (| = workgroup barrier).  The weight stream is packed in this order.
         {
             f32x16 af[ROWS];
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) af[rr] = zero16();
-            Unroll<0, 4>::run([&](auto hcc) {
+            auto hidden_epilogue = [&](auto hcc, f32x16 (&ah)[ROWS]) {
                 constexpr int hc = decltype(hcc)::value;
                 _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
-                f32x16 ah[ROWS];
-#pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
-                gemm16_t<ROWS, ROWH, 64 + 32 * hc>(ring, XH + rd, XL + rd, ah);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bb = vec4(PV + PKV_B1 + 128 * hc, g);
@@ -385,8 +429,51 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 }
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr);
+            };
+            Unroll<0, 4>::run([&](auto hcc) {
+                constexpr int hc = decltype(hcc)::value;
+                f32x16 ah[ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
+                gemm16_t<ROWS, ROWH, (hc == 0 ? 64 : 48 + 32 * hc)>(ring, XH + rd, XL + rd, ah);
+                if constexpr (hc == 0) {
+                    hidden_epilogue(hcc, ah);
+                } else {
+                    constexpr int pc = hc - 1;                       // chunk whose second GEMM runs now
+                    _Float16 *PH = (pc & 1) ? CH : BH, *PL = (pc & 1) ? CL : BL;
+                    _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
+                    f32x4 bb[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bb[g] = vec4(PV + PKV_B1 + 128 * hc, g);
+                    // epilogue of chunk hc in 8 x ROWS x 3 pieces: K-step s handles registers 2s, 2s+1 of each
+                    // row (bias + ReLU | hi | lo and, every second step, the 8-byte stores)
+                    float v0[ROWS], v1[ROWS], t0[ROWS], t1[ROWS];
+                    unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS];
+                    auto side = [&](auto ss, auto rc, auto pp) {
+                        constexpr int st = decltype(ss)::value, rr = decltype(rc)::value, part = decltype(pp)::value;
+                        constexpr int g = st / 2, e = 2 * (st & 1);
+                        if constexpr (part == 0) {
+                            v0[rr] = fmaxf(ah[rr][2 * st] + bb[g][e], 0.0f);
+                            v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
+                        } else if constexpr (part == 1) {
+                            t0[rr] = __uint_as_float(__float_as_uint(v0[rr]) & 0xFFFFE000u);
+                            t1[rr] = __uint_as_float(__float_as_uint(v1[rr]) & 0xFFFFE000u);
+                            hq[rr] = pack_rtz(t0[rr], t1[rr]);
+                        } else {
+                            lq[rr] = pack_rtz(v0[rr] - t0[rr], v1[rr] - t1[rr]);
+                            if constexpr (st & 1) {
+                                *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
+                                *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
+                            } else {
+                                hp[rr] = hq[rr];
+                                lp[rr] = lq[rr];
+                            }
+                        }
+                    };
+                    gemm16_t_with<ROWS, ROWH, 64 + 32 * hc>(ring, PH + rd, PL + rd, af, side);
+                }
                 __syncthreads();
-                gemm16_t<ROWS, ROWH, 80 + 32 * hc>(ring, HH + rd, HL + rd, af);
+                if constexpr (hc == 3) gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);
             });
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

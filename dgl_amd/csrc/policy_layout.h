@@ -5,6 +5,7 @@
 // (64 lanes x 16 B) a wave consumes, in exactly the order it consumes them, so that a wave's
 // weight traffic is one linear read which a register ring prefetches ahead across GEMM boundaries.
 //   per block : 48 fragments q,k,v interleaved by K-step; 16 combine; 4 x (16 W1 + 16 W2)
+//               (f16 stream: W1.0 | W1.1 W2.0 | W1.2 W2.1 | W1.3 W2.2 | W2.3, its pipeline's order)
 //   stream    : block 0 | anchor embedding(s) 2 x 16 (TSP repeats its single one) | blocks 1..3
 // f32 stream : a fragment holds W[32 ot + (lane&31)][8 c + 4 (lane>>5) + e], e = 0..3, as binary32:
 //              four K=2 MFMA steps.
