@@ -110,15 +110,19 @@ def main():
         n_tok, feat, anchors = knn + 1, 7, 1
     decisions = N - 1
 
-    ev_policy, ev_knn = [], []
+    ev_policy, ev_knn, ev_null = [], [], []
 
     def rollout(sample: bool):
         eng.reset()
         eng.step(start)
         s = 0
         while eng.t < N:
-            probe = sample and (s % 16 == 8) and eng.k == knn
+            probe = sample and (s % 16 == 8) and (eng.kd if cvrp else eng.k) == knn
             if probe:
+                # an empty event pair measures what an event boundary itself adds to an interval
+                n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n0.record(); n1.record()
+                ev_null.append((n0, n1))
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
             eng.forward(policy, want_logits=False, want_prob=False)
@@ -156,8 +160,10 @@ def main():
     mean_len = float(stats[0] / stats[1])
 
     if rank == 0:
-        ms_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
-        ms_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
+        ms_null = sum(a.elapsed_time(b) for a, b in ev_null) / max(1, len(ev_null))
+        raw_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
+        raw_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
+        ms_policy, ms_knn = raw_policy - ms_null, raw_knn - ms_null
         flops = policy_flops_per_row(n_tok, feat, anchors) * B
         split = eng.arithmetic == ARITH_SPLIT_F16
         peak_tf = PEAK_F16_MATRIX_TFLOPS / SPLIT_PASSES if split else PEAK_FP32_MATRIX_TFLOPS
@@ -181,13 +187,13 @@ def main():
             "roofline": {"kernel": "policy_kernel_f16" if split else "policy_kernel_f32", "bound": "mfma",
                          "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
                          "traffic": None, "avg_launch_ms": ms_policy, "flops_per_launch": flops,
-                         "samples": len(ev_policy),
+                         "samples": len(ev_policy), "event_interval_ms": raw_policy, "empty_event_interval_ms": ms_null,
                          "peak_note": (f"dense f16 MFMA peak {PEAK_F16_MATRIX_TFLOPS} / {SPLIT_PASSES} passes per "
                                        "f32-accurate product" if split else "dense f32-input MFMA peak"),
                          "frac_of_f16_dense_peak": ach_tf / PEAK_F16_MATRIX_TFLOPS},
             "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
-                             "avg_launch_ms": ms_knn, "bytes_per_launch": bytes_knn, "rows": B},
+                             "avg_launch_ms": ms_knn, "event_interval_ms": raw_knn, "bytes_per_launch": bytes_knn, "rows": B},
         }
         if not args.no_aux and world == 1:
             out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, args.problem, N, knn)
