@@ -331,7 +331,7 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19199)", st->N);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)cvrp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 3) / 4, st->B), dim3(256), lds, (hipStream_t)stream, *st);
+    hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 255) / 256, st->B), dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_cvrp_reset");
     return DGL_OK;
 }

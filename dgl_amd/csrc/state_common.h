@@ -4,9 +4,10 @@
 
 // Row mean / population std of the pairwise distance matrix of one instance, without
 // storing the matrix (TSP/TSPEnv.py:228-235, CVRP/CVRPEnv.py:475-482).
-// grid: (ceil(M / 4), B), block 256 = 4 waves; wave w handles node i = 4*blockIdx.x + w and
-// sums d(i, j) over j in binary64 (rounded once at the end).  The instance's coordinates are
-// staged once per block in LDS (dynamic, 8*M bytes).  Also clears the visited bitmask.
+// grid: (ceil(M / 256), B), block 256; thread t handles node i = 256*blockIdx.x + t and sums
+// d(i, j) over j = 0..M-1 in binary64 (rounded once at the end).  The instance's coordinates are
+// staged once per block in LDS (dynamic, 8*M bytes) and read back as broadcasts (every lane reads
+// the same j).  Also clears the visited bitmask.
 __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, int M, int rows_per_instance,
                                                float *__restrict__ avg, float *__restrict__ sd,
                                                uint64_t *__restrict__ visited) {
@@ -15,23 +16,23 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, int
     const float *xyb = xy + (size_t)b * M * 2;
     for (int e = threadIdx.x; e < 2 * M; e += blockDim.x) lds_xy[e] = xyb[e];
     __syncthreads();
-    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) {
         const float xi = lds_xy[2 * i], yi = lds_xy[2 * i + 1], ni = dgl_sqnorm(xi, yi);
+        const float2 *pts = reinterpret_cast<const float2 *>(lds_xy);
         double s = 0.0, q = 0.0;
-        for (int j = lane; j < M; j += 64) {
-            float xj = lds_xy[2 * j], yj = lds_xy[2 * j + 1];
-            double d = (double)dgl_chain_dist(xi, yi, ni, xj, yj, dgl_sqnorm(xj, yj));
+#pragma unroll 4
+        for (int j = 0; j < M; ++j) {
+            const float2 pj = pts[j];
+            const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
             s += d;
             q = fma(d, d, q);
         }
-        s = wave_sum_f64(s);
-        q = wave_sum_f64(q);
-        double mean = s / M;
-        double var = q / M - mean * mean;
-        float favg = (float)mean, fsd = (float)sqrt(var > 0.0 ? var : 0.0);
-        for (int p = lane; p < rows_per_instance; p += 64) {
-            size_t r = (size_t)b * rows_per_instance + p;
+        const double mean = s / M;
+        const double var = q / M - mean * mean;
+        const float favg = (float)mean, fsd = (float)sqrt(var > 0.0 ? var : 0.0);
+        for (int p = 0; p < rows_per_instance; ++p) {
+            const size_t r = (size_t)b * rows_per_instance + p;
             avg[r * M + i] = favg;
             sd[r * M + i] = fsd;
         }

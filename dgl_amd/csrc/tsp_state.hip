@@ -13,7 +13,7 @@
 #define TSP_F 7
 
 // --------------------------------------------------------------------------- reset
-// grid: (ceil(N / 4), B), block 256 = 4 waves (see dgl_reset_rows in state_common.h)
+// grid: (ceil(N / 256), B), block 256 (see dgl_reset_rows in state_common.h)
 __global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
     dgl_reset_rows(st.xy, st.N, st.rows_per_instance, st.avg, st.sd, st.visited);
 }
@@ -240,7 +240,7 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)tsp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((st->N + 3) / 4, st->B);
+    dim3 grid((st->N + 255) / 256, st->B);
     hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_tsp_reset");
     return DGL_OK;
