@@ -45,7 +45,7 @@ class PolicyWeights(Structure):
 class PolicyIO(Structure):
     _fields_ = [("problem", c_int32), ("R", c_int32), ("n", c_int32), ("k_last", c_int32), ("N", c_int32),
                 ("idx_stride", c_int32), ("idx_dep_stride", c_int32), ("tile_row_stride", c_int32),
-                ("arithmetic", c_int32), ("reserved", c_int32),
+                ("arithmetic", c_int32), ("out_stride", c_int32),
                 ("tile", c_void_p), ("idx_last", c_void_p), ("idx_depot", c_void_p), ("infeasible", c_void_p),
                 ("logits_out", c_void_p), ("prob_out", c_void_p), ("selected_out", c_void_p)]
 
@@ -71,6 +71,11 @@ SIGNATURES = {
     "dgl_policy_packed_floats": (c_int64, [c_int32]),
     "dgl_policy_pack": (c_int32, [POINTER(PolicyWeights), c_void_p, c_void_p]),
     "dgl_policy_forward": (c_int32, [c_void_p, POINTER(PolicyIO), c_void_p]),
+    "dgl_policy_general_workspace_floats": (c_int64, [c_int32, c_int32]),
+    "dgl_policy_general": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
+                                     c_float, c_void_p, c_void_p, c_void_p]),
+    "dgl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_float,
+                                c_float, c_float, c_float, c_void_p]),
     "dgl_policy_scatter_probs": (c_int32, [POINTER(PolicyIO), c_void_p, c_void_p, c_int32, c_void_p]),
     "dgl_beam_advance": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p]),

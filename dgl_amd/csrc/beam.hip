@@ -15,7 +15,7 @@
 #define BEAM_THREADS 256
 #define BEAM_MAX 256
 #define DENSE_CAP 2048      // candidate keys kept in LDS by the dense kernel
-#define COMPACT_CAP 8192    // beam * DGL_MAX_TOKENS upper bound for the compact kernel
+#define COMPACT_CAP 8192    // beam * tokens upper bound for the compact kernel
 
 typedef unsigned long long u64;
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
             const int b = e / n, tok = e % n, r = g * beam + b;
             const int act = token_action(io, r, tok);
             if (act >= 0) {
-                const float lpv = logf(prob[(size_t)r * DGL_MAX_TOKENS + tok]);
+                const float lpv = logf(prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok]);
                 const float v = step >= 2 ? __fadd_rn(lpv, sc[b]) : (b == 0 ? lpv : -1e20f);
                 k = make_key(v, (unsigned)b * (unsigned)A + (unsigned)act);
             }
@@ -226,7 +226,8 @@ extern "C" int dgl_beam_advance_compact(const dgl_policy_io_t *io, const float *
     DGL_CHECK_ARG(G > 0 && beam >= 1 && step >= 1, "bad sizes G=%d beam=%d step=%d", G, beam, step);
     DGL_CHECK_ARG(beam <= BEAM_MAX, "beam=%d exceeds the supported maximum %d", beam, BEAM_MAX);
     DGL_CHECK_ARG(io->R == G * beam, "io->R=%d != G*beam=%d", io->R, G * beam);
-    DGL_CHECK_ARG(io->n >= 2 && io->n <= DGL_MAX_TOKENS && io->idx_last != nullptr, "bad policy io");
+    DGL_CHECK_ARG(io->n >= 2 && io->n <= (io->out_stride > 0 ? io->out_stride : DGL_MAX_TOKENS) && io->idx_last != nullptr,
+                  "bad policy io");
     const int need = io->problem == DGL_PROBLEM_TSP ? io->N : 2 * (io->N + 1);
     DGL_CHECK_ARG(A == need, "A=%d but the action space is %d", A, need);
     DGL_CHECK_ARG(A >= beam, "A=%d < beam=%d", A, beam);

@@ -434,15 +434,15 @@ __global__ void scatter_probs_kernel(dgl_policy_io_t io, const float *__restrict
             act = io.idx_last[(size_t)r * io.idx_stride + tok];
         else
             act = io.idx_depot[(size_t)r * io.idx_dep_stride + (tok - io.k_last - 1)] + io.N + 1;
-        drow[act] = prob[(size_t)r * DGL_MAX_TOKENS + tok];
+        drow[act] = prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok];
     }
 }
 
-static int check_io(const dgl_policy_io_t *io) {
+static int check_io(const dgl_policy_io_t *io, int max_n = DGL_MAX_TOKENS) {
     DGL_CHECK_ARG(io != nullptr, "io is NULL");
     DGL_CHECK_ARG(io->problem == DGL_PROBLEM_TSP || io->problem == DGL_PROBLEM_CVRP, "unknown problem %d", io->problem);
     DGL_CHECK_ARG(io->R > 0, "R=%d", io->R);
-    DGL_CHECK_ARG(io->n >= 2 && io->n <= DGL_MAX_TOKENS, "n=%d tokens per row outside [2,%d]", io->n, DGL_MAX_TOKENS);
+    DGL_CHECK_ARG(io->n >= 2 && io->n <= max_n, "n=%d tokens per row outside [2,%d]", io->n, max_n);
     if (io->problem == DGL_PROBLEM_TSP) {
         DGL_CHECK_ARG(io->k_last == io->n - 1, "TSP needs k_last == n-1 (k_last=%d n=%d)", io->k_last, io->n);
     } else {
@@ -471,6 +471,8 @@ extern "C" int dgl_policy_forward(const float *packed_weights, const dgl_policy_
     DGL_CHECK_ARG(packed_weights != nullptr, "packed_weights is NULL");
     if (int e = check_io(io)) return e;
     DGL_CHECK_ARG(io->tile != nullptr, "tile is NULL");
+    DGL_CHECK_ARG(io->out_stride == 0 || io->out_stride == DGL_MAX_TOKENS, "the fused kernels write %d floats per row",
+                  DGL_MAX_TOKENS);
     DGL_CHECK_ARG(io->tile_row_stride >= io->n * DGL_TILE_STRIDE, "tile_row_stride %d < n*%d", io->tile_row_stride,
                   DGL_TILE_STRIDE);
     // two rows per workgroup share every weight fragment; a single row per workgroup
@@ -485,7 +487,7 @@ extern "C" int dgl_policy_forward(const float *packed_weights, const dgl_policy_
 
 extern "C" int dgl_policy_scatter_probs(const dgl_policy_io_t *io, const float *prob, float *dense_out, int32_t A,
                                         dgl_stream_t stream) {
-    if (int e = check_io(io)) return e;
+    if (int e = check_io(io, io && io->out_stride > 0 ? io->out_stride : DGL_MAX_TOKENS)) return e;
     DGL_CHECK_ARG(prob != nullptr && dense_out != nullptr, "NULL argument");
     const int need = io->problem == DGL_PROBLEM_TSP ? io->N : 2 * (io->N + 1);
     DGL_CHECK_ARG(A == need, "A=%d but the action space is %d", A, need);

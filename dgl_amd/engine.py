@@ -29,6 +29,30 @@ def default_arithmetic() -> int:
     raise ValueError(f"DGL_ARITHMETIC={name!r}: expected 'split_f16' or 'f32'")
 
 
+def weights_struct(sd: Dict[str, torch.Tensor], problem: int) -> _lib.PolicyWeights:
+    """dgl_policy_weights_t over device tensors keyed like the reference's state_dict
+    (TSP/TSPModel.py:238-339, CVRP/CVRPModel.py:378-427)."""
+    w = _lib.PolicyWeights()
+    w.problem = problem
+    w.emb_w, w.emb_b = ptr(sd["encoder.embedding.weight"]), ptr(sd["encoder.embedding.bias"])
+    for i, pre in enumerate(_BLOCKS):
+        b = w.block[i]
+        b.wq, b.wk, b.wv = ptr(sd[pre + "Wq.weight"]), ptr(sd[pre + "Wk.weight"]), ptr(sd[pre + "Wv.weight"])
+        b.wc, b.bc = ptr(sd[pre + "multi_head_combine.weight"]), ptr(sd[pre + "multi_head_combine.bias"])
+        b.w1, b.b1 = ptr(sd[pre + "feedForward.W1.weight"]), ptr(sd[pre + "feedForward.W1.bias"])
+        b.w2, b.b2 = ptr(sd[pre + "feedForward.W2.weight"]), ptr(sd[pre + "feedForward.W2.bias"])
+    for a, nm in enumerate(anchor_names(problem)):
+        w.anchor_w[a], w.anchor_b[a] = ptr(sd[nm + ".weight"]), ptr(sd[nm + ".bias"])
+    w.final_w, w.final_b = ptr(sd["decoder.Linear_final.weight"]), ptr(sd["decoder.Linear_final.bias"])
+    return w
+
+
+def anchor_names(problem: int):
+    if problem == PROBLEM_TSP:
+        return ["decoder.embedding_last_node", "decoder.embedding_last_node"]
+    return ["decoder.embedding_last_node_not_via_depot", "decoder.embedding_last_node_via_depot"]
+
+
 class PackedPolicy:
     """Weights of TSPModel / CVRPModel re-laid out for the MFMA kernel.
 
@@ -44,26 +68,32 @@ class PackedPolicy:
         if tuple(sd["encoder.embedding.weight"].shape) != (128, feat):
             raise ValueError(f"encoder.embedding.weight has shape {tuple(sd['encoder.embedding.weight'].shape)}, "
                              f"expected (128, {feat})")
-        w = _lib.PolicyWeights()
-        w.problem = problem
-        w.emb_w, w.emb_b = ptr(sd["encoder.embedding.weight"]), ptr(sd["encoder.embedding.bias"])
-        for i, pre in enumerate(_BLOCKS):
-            b = w.block[i]
-            b.wq, b.wk, b.wv = ptr(sd[pre + "Wq.weight"]), ptr(sd[pre + "Wk.weight"]), ptr(sd[pre + "Wv.weight"])
-            b.wc, b.bc = ptr(sd[pre + "multi_head_combine.weight"]), ptr(sd[pre + "multi_head_combine.bias"])
-            b.w1, b.b1 = ptr(sd[pre + "feedForward.W1.weight"]), ptr(sd[pre + "feedForward.W1.bias"])
-            b.w2, b.b2 = ptr(sd[pre + "feedForward.W2.weight"]), ptr(sd[pre + "feedForward.W2.bias"])
-        if problem == PROBLEM_TSP:
-            names = ["decoder.embedding_last_node", "decoder.embedding_last_node"]
-        else:
-            names = ["decoder.embedding_last_node_not_via_depot", "decoder.embedding_last_node_via_depot"]
-        for a, nm in enumerate(names):
-            w.anchor_w[a], w.anchor_b[a] = ptr(sd[nm + ".weight"]), ptr(sd[nm + ".bias"])
-        w.final_w, w.final_b = ptr(sd["decoder.Linear_final.weight"]), ptr(sd["decoder.Linear_final.bias"])
+        self.sd = sd                                 # raw weights stay resident: the general (n > 32 tokens) path reads them
+        self.w = w = weights_struct(sd, problem)
         self.packed = torch.empty(lib.dgl_policy_packed_floats(problem), dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             check(lib.dgl_policy_pack(ctypes.byref(w), ptr(self.packed), stream_ptr()), "dgl_policy_pack")
             torch.cuda.current_stream().synchronize()      # sd may be freed after this returns
+
+
+def general_workspace(engine, R: int, n: int) -> torch.Tensor:
+    """Scratch of dgl_policy_general for R rows of n tokens, cached on the engine."""
+    need = engine.lib.dgl_policy_general_workspace_floats(R, n)
+    ws = getattr(engine, "_general_ws", None)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=engine.device)
+        engine._general_ws = ws
+    return ws
+
+
+def policy_forward(engine, policy: PackedPolicy, io: _lib.PolicyIO) -> None:
+    """The fused kernels for rows of at most 32 tokens, the general path otherwise."""
+    if engine.out_w == MAX_TOKENS:
+        check(engine.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+    else:
+        ws = general_workspace(engine, io.R, io.n)
+        check(engine.lib.dgl_policy_general(ctypes.byref(policy.w), None, ctypes.byref(io), 0, 0.0, ptr(ws), 0,
+                                            stream_ptr()), "dgl_policy_general")
 
 
 class TspEngine:
@@ -86,13 +116,21 @@ class TspEngine:
         self.cur = 0
         self.idx = torch.empty(R, knn, dtype=torch.int32, device=dev)
         self.tile = torch.zeros(R, (knn + 1) * TILE_STRIDE, dtype=torch.float32, device=dev)
-        self.logits = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
-        self.prob = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self._alloc_outputs()
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
         self.t = 0
         self.tile_t = -1                 # step count the neighbourhood buffers (idx, tile) belong to
         self._beam_bufs = None
+
+    def _alloc_outputs(self) -> None:
+        """logits / prob rows hold one float per token: 32 for the fused kernels, more for larger neighbourhoods."""
+        w = max(MAX_TOKENS, self.knn + 1)
+        if getattr(self, "out_w", None) != w:
+            self.out_w = w
+            self.out_stride = 0 if w == MAX_TOKENS else w
+            self.logits = torch.zeros(self.R, w, dtype=torch.float32, device=self.device)
+            self.prob = torch.zeros(self.R, w, dtype=torch.float32, device=self.device)
 
     def set_knn(self, knn: int) -> None:
         """Change the neighbourhood size (re-allocates the per-step scratch)."""
@@ -102,6 +140,7 @@ class TspEngine:
         self.idx = torch.empty(self.R, knn, dtype=torch.int32, device=self.device)
         self.tile = torch.zeros(self.R, (knn + 1) * TILE_STRIDE, dtype=torch.float32, device=self.device)
         self.tile_t = -1
+        self._alloc_outputs()
 
     def ensure_neighbourhood(self) -> None:
         """Build idx/tile for the current state if the last step did not (dgl_tsp_knn)."""
@@ -149,13 +188,12 @@ class TspEngine:
     def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
         k = self.k
         return _lib.PolicyIO(PROBLEM_TSP, self.R, k + 1, k, self.N, self.knn, 0, (self.knn + 1) * TILE_STRIDE,
-                             self.arithmetic, 0, ptr(self.tile), ptr(self.idx), 0, 0,
+                             self.arithmetic, self.out_stride, ptr(self.tile), ptr(self.idx), 0, 0,
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)
 
     def forward(self, policy: PackedPolicy, **kw) -> None:
-        io = self.policy_io(**kw)
-        check(self.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+        policy_forward(self, policy, self.policy_io(**kw))
 
     def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
@@ -248,12 +286,19 @@ class CvrpEngine:
         self.idx_dep = torch.empty(R, depot_knn, dtype=torch.int32, device=dev)
         self.infeasible = torch.zeros(R, knn, dtype=torch.uint8, device=dev)
         self.tile = torch.zeros(R, self.ntok_max * TILE_STRIDE, dtype=torch.float32, device=dev)
-        self.logits = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
-        self.prob = torch.zeros(R, MAX_TOKENS, dtype=torch.float32, device=dev)
+        self._alloc_outputs()
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
         self.t = 0
         self.tile_t = -1
+
+    def _alloc_outputs(self) -> None:
+        w = max(MAX_TOKENS, self.ntok_max)
+        if getattr(self, "out_w", None) != w:
+            self.out_w = w
+            self.out_stride = 0 if w == MAX_TOKENS else w
+            self.logits = torch.zeros(self.R, w, dtype=torch.float32, device=self.device)
+            self.prob = torch.zeros(self.R, w, dtype=torch.float32, device=self.device)
 
     def set_knn(self, knn: int, depot_knn: int) -> None:
         if knn == self.knn and depot_knn == self.depot_knn:
@@ -266,6 +311,7 @@ class CvrpEngine:
         self.infeasible = torch.zeros(R, knn, dtype=torch.uint8, device=dev)
         self.tile = torch.zeros(R, self.ntok_max * TILE_STRIDE, dtype=torch.float32, device=dev)
         self.tile_t = -1
+        self._alloc_outputs()
 
     def ensure_neighbourhood(self) -> None:
         """Build both neighbourhoods and the tile for the current state if the last step did not
@@ -321,14 +367,13 @@ class CvrpEngine:
     def policy_io(self, want_logits=True, want_prob=True, want_selected=True) -> _lib.PolicyIO:
         kl, kd = self.kl, self.kd
         return _lib.PolicyIO(PROBLEM_CVRP, self.R, kl + kd + 2, kl, self.N, self.knn, self.depot_knn,
-                             self.ntok_max * TILE_STRIDE, self.arithmetic, 0, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
+                             self.ntok_max * TILE_STRIDE, self.arithmetic, self.out_stride, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
                              ptr(self.infeasible),
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)
 
     def forward(self, policy: PackedPolicy, **kw) -> None:
-        io = self.policy_io(**kw)
-        check(self.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+        policy_forward(self, policy, self.policy_io(**kw))
 
     def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         A = 2 * (self.N + 1)

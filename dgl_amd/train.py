@@ -1,0 +1,115 @@
+"""Teacher-forced training step of the reference's trainers on the device
+(CVRP/CVRPTrainer.py:232-282, TSP/TSPTrainer.py): forward in mode 'train' -> probability of the
+teacher's action, loss = -log(prob).mean(), backward, gradient all-reduce over the ranks of a
+torch.distributed job, Adam.  The arithmetic runs in libdgl_amd (dgl_policy_general,
+dgl_adam_step); this module owns the flat parameter / gradient / moment vectors.
+
+Only the tensors the forward pass uses take part: ``decoder.embedding_last_node_pos`` and
+``decoder.k_1`` exist in the checkpoint but never receive a gradient, and torch.optim.Adam skips
+parameters without one (no weight decay either), so they are carried through unchanged.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import PROBLEM_TSP, check, ptr, stream_ptr
+from .engine import general_workspace, weights_struct
+
+UNUSED = ("decoder.embedding_last_node_pos.", "decoder.k_1.")
+
+
+class PolicyTrainer:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], problem: int, device: torch.device, lr: float = 1e-4,
+                 weight_decay: float = 1e-6, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.lib = _lib.load()
+        self.problem, self.device = problem, device
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.keys = [k for k in state_dict if not k.startswith(UNUSED)]
+        self.unused = {k: v.detach().clone() for k, v in state_dict.items() if k.startswith(UNUSED)}
+        self.order = list(state_dict.keys())
+        sizes = [state_dict[k].numel() for k in self.keys]
+        self.numel = sum(sizes)
+        self.params = torch.empty(self.numel, dtype=torch.float32, device=device)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.views, self.grad_views = {}, {}
+        off = 0
+        for k, n in zip(self.keys, sizes):
+            shape = tuple(state_dict[k].shape)
+            self.views[k] = self.params[off:off + n].view(shape)
+            self.grad_views[k] = self.grads[off:off + n].view(shape)
+            self.views[k].copy_(state_dict[k].to(device=device, dtype=torch.float32))
+            off += n
+        self.w = weights_struct(self.views, problem)
+        self.g = weights_struct(self.grad_views, problem)
+        self.step_count = 0
+
+    # ---- checkpoint interchange -----------------------------------------------------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k in self.order:
+            out[k] = (self.views[k] if k in self.views else self.unused[k]).detach().clone()
+        return out
+
+    def gradient_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().clone() for k, v in self.grad_views.items()}
+
+    # ---- one decode step ------------------------------------------------------------------
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+
+    def forward_backward(self, engine, teacher: torch.Tensor, global_rows: Optional[int] = None) -> torch.Tensor:
+        """model(state, ..., mode='train') + loss.backward() for the engine's current tile: returns the
+        teacher's probability per row [R]; gradients of -log(prob).mean() (mean over ``global_rows``,
+        default the engine's rows times the world size) are added to ``self.grads``."""
+        io = engine.policy_io(want_logits=False, want_prob=False, want_selected=False)
+        if global_rows is None:
+            global_rows = io.R * world_size()
+        ws = general_workspace(engine, io.R, io.n)
+        prob = torch.empty(io.R, dtype=torch.float32, device=self.device)
+        teacher = teacher.to(device=self.device, dtype=torch.int32).contiguous()
+        check(self.lib.dgl_policy_general(ctypes.byref(self.w), ctypes.byref(self.g), ctypes.byref(io), ptr(teacher),
+                                          1.0 / float(global_rows), ptr(ws), ptr(prob), stream_ptr()),
+              "dgl_policy_general")
+        return prob
+
+    def optimizer_step(self) -> None:
+        """Gradient all-reduce (sum over ranks; the per-rank gradients already carry 1/global_rows) and Adam."""
+        if world_size() > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM)
+        self.step_count += 1
+        b1, b2 = self.betas
+        check(self.lib.dgl_adam_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                     self.numel, self.step_count, self.lr, b1, b2, self.eps, self.weight_decay, 1.0,
+                                     stream_ptr()), "dgl_adam_step")
+
+
+def world_size() -> int:
+    d = torch.distributed
+    return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+
+def train_one_batch_cvrp(trainer: PolicyTrainer, engine, solution: torch.Tensor, solution_flag: torch.Tensor) -> float:
+    """CVRPTrainer._train_one_batch (CVRP/CVRPTrainer.py:232-282) on a reset engine: ``solution`` [R][N]
+    customer ids (1..N) in visiting order, ``solution_flag`` [R][N] 1 where the move goes via the depot.
+    One Adam update per decode step.  Returns -log(prob_list).mean() over all steps after the first."""
+    N = engine.N
+    dev = engine.device
+    act = (solution + solution_flag * (N + 1)).to(device=dev, dtype=torch.int32)
+    engine.reset()
+    engine.step(act[:, 0].contiguous())
+    logs = []
+    for t in range(1, N):
+        trainer.zero_grad()
+        prob = trainer.forward_backward(engine, act[:, t].contiguous())
+        trainer.optimizer_step()
+        logs.append(prob.double().log())
+        engine.step(act[:, t].contiguous())
+    lp = torch.stack(logs, 1)
+    # the reference's prob_list also holds the ones of the first step (log 1 = 0)
+    return float(-(lp.sum() / (lp.numel() + lp.shape[0])))

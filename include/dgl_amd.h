@@ -210,7 +210,7 @@ typedef struct {
     int32_t idx_dep_stride;
     int32_t tile_row_stride; /* floats between consecutive rows of `tile` (>= n*DGL_TILE_STRIDE) */
     int32_t arithmetic;   /* DGL_ARITH_* : how the dense contractions are evaluated */
-    int32_t reserved;     /* 0 */
+    int32_t out_stride;   /* floats per row of logits_out / prob_out; 0 = DGL_MAX_TOKENS */
     const float *tile;
     const int32_t *idx_last;    /* [R][idx_stride] */
     const int32_t *idx_depot;   /* [R][idx_dep_stride] (CVRP) */
@@ -229,6 +229,39 @@ DGL_API int dgl_policy_forward(const float *packed_weights, const dgl_policy_io_
  * 2(N+1) (CVRP). */
 DGL_API int dgl_policy_scatter_probs(const dgl_policy_io_t *io, const float *prob, float *dense_out,
                              int32_t A, dgl_stream_t stream);
+
+/* ------------------------------------------------------- general forward / training step
+ * The same network for ANY number of tokens per row (2 <= n <= 256; e.g. knn = depot_knn = 100,
+ * CVRP/train.py:130-131), evaluated as a sequence of plain f32 matrix kernels over the flattened
+ * token axis, and its backward pass: the model side of CVRPTrainer._train_one_batch
+ * (CVRP/CVRPTrainer.py:268-271: model(...) in mode 'train' -> probability of the teacher's
+ * action, CVRP/CVRPModel.py:311-345 / TSP/TSPModel.py:206-217; loss = -log(prob).mean();
+ * loss.backward()).
+ *  w     : raw weights (device pointers, reference state_dict layout), as for dgl_policy_pack.
+ *  grad  : NULL = inference only.  Otherwise the same struct over gradient buffers (one per
+ *          tensor, same shapes, pointers cast to const float*): gradients are ADDED to them
+ *          (float atomics), so zero them first (model.zero_grad()).
+ *  teacher [R] (may be NULL when grad is NULL): the teacher's action per row (TSP node id; CVRP
+ *          node id, + N+1 when the move goes via the depot).  teacher_prob_out [R] (may be NULL)
+ *          receives the floored probability of that action, 1e-20 when it is not a candidate
+ *          token (the dense tensor the reference indexes holds 1e-20 there).
+ *  grad_scale: d(loss)/d(-log p_r), i.e. 1 / (rows of the global batch) for the reference's mean.
+ *  ws    : dgl_policy_general_workspace_floats(R, n) floats of scratch (activations are kept
+ *          there between the forward and the backward half of the call).
+ *  io    : as for dgl_policy_forward (logits_out / prob_out / selected_out are written when
+ *          given, with io->out_stride floats per row); io->arithmetic is ignored (binary32). */
+DGL_API int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n);
+DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
+                               const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,
+                               float *ws, float *teacher_prob_out, dgl_stream_t stream);
+
+/* optimizer.step() of torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures
+ * it (CVRP/train.py:49-54, CVRP/CVRPTrainer.py:272) over a flat parameter vector of n floats;
+ * step = 1, 2, ... ; grads are multiplied by grad_scale first (1/world_size after a sum
+ * all-reduce). */
+DGL_API int dgl_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                          int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          float grad_scale, dgl_stream_t stream);
 
 /* ----------------------------------------------------------------------- beam
  * Beamsearch.advance (utils/beamsearch.py:52-131) on dense log-probabilities:

@@ -510,3 +510,23 @@ def random_weights(problem: str, seed: int, scale: float = 1.0) -> Dict[str, Ten
         bound = scale / math.sqrt(fan_in)
         out[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
     return out
+
+
+# --------------------------------------------------------------------------- training step
+def enable_grad(weights: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Leaf copies of the weights that record gradients (the reference's nn.Parameters)."""
+    return {k: v.detach().clone().requires_grad_(True) for k, v in weights.items()}
+
+
+def train_forward_backward(oracle, teacher: Tensor):
+    """Model side of CVRPTrainer._train_one_batch / TSPTrainer (CVRP/CVRPTrainer.py:268-271,
+    CVRP/CVRPModel.py:311-345, TSP/TSPModel.py:206-217): probability of the teacher's action from the
+    dense tensor, loss = -log(prob.double()).mean(), backward through ``oracle.w`` (which must hold
+    gradient-recording leaves).  Returns (prob [R], loss)."""
+    for v in oracle.w.values():
+        v.grad = None
+    out = oracle.forward()
+    prob = out["probs"][torch.arange(oracle.R)[:, None], teacher.long()[:, None]].reshape(-1)
+    loss = -prob.type(torch.float64).log().mean()
+    loss.backward()
+    return prob.detach(), float(loss.detach())
