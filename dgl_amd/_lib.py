@@ -29,7 +29,8 @@ class TspState(Structure):
 class CvrpState(Structure):
     _fields_ = [("B", c_int32), ("N", c_int32), ("rows_per_instance", c_int32), ("R", c_int32),
                 ("xy", c_void_p), ("demand", c_void_p), ("avg", c_void_p), ("sd", c_void_p),
-                ("capacity", c_void_p), ("visited", c_void_p), ("nodes", c_void_p), ("flags", c_void_p)]
+                ("capacity", c_void_p), ("visited", c_void_p), ("nodes", c_void_p), ("flags", c_void_p),
+                ("demand_in_distance", c_int32)]
 
 
 class BlockWeights(Structure):

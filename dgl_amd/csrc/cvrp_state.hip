@@ -12,7 +12,8 @@
 #define CVRP_F 8       // x, y, demand, d, avg, sd, sin, cos (+ group flag in column 8 of the tile)
 
 __global__ __launch_bounds__(256) void cvrp_reset_kernel(dgl_cvrp_state_t st) {
-    dgl_reset_rows(st.xy, st.N + 1, st.rows_per_instance, st.avg, st.sd, st.visited);
+    dgl_reset_rows(st.xy, st.demand_in_distance ? st.demand : nullptr, st.N + 1, st.rows_per_instance, st.avg, st.sd,
+                   st.visited);
     if (blockIdx.x == 0)
         for (int p = threadIdx.x; p < st.rows_per_instance; p += blockDim.x)
             st.capacity[(size_t)blockIdx.y * st.rows_per_instance + p] = 1.0f;
@@ -20,20 +21,35 @@ __global__ __launch_bounds__(256) void cvrp_reset_kernel(dgl_cvrp_state_t st) {
 
 struct CvrpRowCtx {
     const float *xyb, *demb;
-    float xc, yc, nc, x0, y0, n0;
+    float xc, yc, zc, nc, x0, y0, n0;       // current node (zc = its demand, used when D3), depot (demand 0)
     size_t rowM;
 };
 
+// D3: distances over (x, y, demand) as the training reset builds them (CVRP/CVRPEnv.py:519:
+// cdist over all three columns of the instance): |p|^2 = (x^2 + y^2) + z^2 and one more FMA in the
+// product chain.  The depot's demand is 0, so its products need no third term.
+template <bool D3>
+__device__ __forceinline__ float cvrp_norm(float x, float y, float z) {
+    const float n = dgl_sqnorm(x, y);
+    return D3 ? __fadd_rn(n, __fmul_rn(z, z)) : n;
+}
+template <bool D3>
+__device__ __forceinline__ float cvrp_cross(float xi, float yi, float zi, float xj, float yj, float zj) {
+    const float c = dgl_chain_cross(xi, yi, xj, yj);
+    return D3 ? __fmaf_rn(-2.0f * zi, zj, c) : c;
+}
+
 // raw data row of a node at p with demand dem and running statistics (a, sd)
 // (CVRP/CVRPEnv.py:696,718,746,782,801); returns d(j, depot)
+template <bool D3>
 __device__ __forceinline__ float cvrp_row(const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
-    const float nj = dgl_sqnorm(p.x, p.y);
+    const float nj = cvrp_norm<D3>(p.x, p.y, dem);
     const float d0 = dgl_chain_dist(p.x, p.y, nj, cx.x0, cx.y0, cx.n0);    // d(j, depot)
     const float den = __fadd_rn(d0, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
     f[2] = dem;
-    f[3] = dgl_chain_dist(p.x, p.y, nj, cx.xc, cx.yc, cx.nc);               // d(j, current)
+    f[3] = dgl_sqrt(dgl_chain_sq(cvrp_cross<D3>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
     f[4] = a;
     f[5] = sd;
     f[6] = __fdiv_rn(__fsub_rn(cx.y0, p.y), den);
@@ -41,15 +57,16 @@ __device__ __forceinline__ float cvrp_row(const CvrpRowCtx &cx, float2 p, float 
     return d0;
 }
 
+template <bool D3>
 __device__ __forceinline__ float cvrp_features(const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
-    return cvrp_row(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], cx.demb[j], st.avg[cx.rowM + j],
+    return cvrp_row<D3>(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], cx.demb[j], st.avg[cx.rowM + j],
                     st.sd[cx.rowM + j], f);
 }
 
 #define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
 
 // One wave per row.  LDS per wave: keysL[M] + keysD[M] + tile[(knn+depot_knn+2)*STRIDE] + scratch[128].
-template <int WAVES, bool UPDATE>
+template <int WAVES, bool UPDATE, bool D3>
 __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
@@ -81,7 +98,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     float cap = !UPDATE ? cap_old : (via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur));
     const float cap_eps = __fadd_rn(cap, 0.000001f);          // feasibility uses the un-nudged capacity
 
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = dem_cur; cx.nc = cvrp_norm<D3>(cx.xc, cx.yc, cx.zc);
     cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
 
     const int u = M - t;                                       // CVRP/CVRPEnv.py:662 (>= 1: t <= N)
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     // (clamped addresses keep them unconditional).
     struct Group {
         float2 p[STEP_UNROLL];
-        float a0[STEP_UNROLL], s0[STEP_UNROLL];
+        float a0[STEP_UNROLL], s0[STEP_UNROLL], dm[STEP_UNROLL];
     };
     auto request = [&](int j0, Group &g) {
 #pragma unroll
@@ -104,6 +121,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
             const int j = min(j0 + 64 * q + lane, M - 1);
             g.p[q] = xy2[j];
             if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
+            g.dm[q] = D3 ? cx.demb[j] : 0.0f;
         }
     };
     Group nxt;
@@ -119,8 +137,8 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             if (j < M) {
-                const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
-                const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
+                const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3>(x, y, g.dm[q]);
+                const float cross = cvrp_cross<D3>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
                     const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));                  // dis[j][cur]
                     const float a0 = g.a0[q], s0 = g.s0[q];
@@ -194,21 +212,21 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kl, &rank);
         if (pick || anchor_early) {
             float *f = tileL + (pick ? rank : kl) * DGL_TILE_STRIDE;
-            cvrp_row(cx, p, dm, av, sv, f);
+            cvrp_row<D3>(cx, p, dm, av, sv, f);
             if (pick) {
                 il[rank] = cj;
                 finish_last(f, rank);
             }
         }
-        if (c == 64 && lane == 63) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     } else {
         wave_select_general(keysL, M, kl, scratch, [&](int j, int rank) {
             il[rank] = j;
             float *f = tileL + rank * DGL_TILE_STRIDE;
-            cvrp_features(st, cx, j, f);
+            cvrp_features<D3>(st, cx, j, f);
             finish_last(f, rank);
         });
-        if (lane == 63) cvrp_features(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+        if (lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     }
     wave_lds_sync();                                           // scratch is reused by the second search
     // neighbourhood of the depot: column 3 holds distance_to_depot (CVRP/CVRPModel.py:180-183)
@@ -222,20 +240,20 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kd, &rank);
         if (pick || anchor_early) {
             float *f = tileD + (pick ? rank : kd) * DGL_TILE_STRIDE;
-            const float d0 = cvrp_row(cx, p, dm, av, sv, f);
+            const float d0 = cvrp_row<D3>(cx, p, dm, av, sv, f);
             if (pick) {
                 id[rank] = cj;
                 f[3] = d0;
             }
         }
-        if (c == 64 && lane == 63) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     } else {
         wave_select_general(keysD, M, kd, scratch, [&](int j, int rank) {
             id[rank] = j;
             float *f = tileD + rank * DGL_TILE_STRIDE;
-            f[3] = cvrp_features(st, cx, j, f);
+            f[3] = cvrp_features<D3>(st, cx, j, f);
         });
-        if (lane == 63) cvrp_features(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+        if (lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     }
     for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
     for (int e = kd + lane; e < depot_knn; e += 64) id[e] = -1;
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
+template <bool D3>
 __global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__restrict__ out) {
     const int r = blockIdx.y, N = st.N, M = N + 1;
     const int b = r / st.rows_per_instance;
@@ -258,11 +277,11 @@ __global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__rest
     cx.demb = st.demand + (size_t)b * M;
     cx.rowM = (size_t)r * M;
     const int cur = st.nodes[(size_t)r * N + (t - 1)];
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = cx.demb[cur]; cx.nc = cvrp_norm<D3>(cx.xc, cx.yc, cx.zc);
     cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
         float f[CVRP_F];
-        cvrp_features(st, cx, j, f);
+        cvrp_features<D3>(st, cx, j, f);
         float *o = out + (cx.rowM + j) * CVRP_F;
 #pragma unroll
         for (int c = 0; c < CVRP_F; ++c) o[c] = f[c];
@@ -327,8 +346,8 @@ static int check_cvrp_state(const dgl_cvrp_state_t *st) {
 extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     if (int e = check_cvrp_state(st)) return e;
     const int M = st->N + 1;
-    size_t lds = (size_t)M * 2 * sizeof(float);
-    DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19199)", st->N);
+    size_t lds = (size_t)M * (st->demand_in_distance ? 3 : 2) * sizeof(float);
+    DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset", st->N);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)cvrp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 255) / 256, st->B), dim3(256), lds, (hipStream_t)stream, *st);
@@ -336,7 +355,7 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     return DGL_OK;
 }
 
-template <bool UPDATE>
+template <bool UPDATE, bool D3>
 static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
                             int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
                             dgl_stream_t stream, const char *what) {
@@ -345,7 +364,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     // few rows: one wave per workgroup spreads them over all CUs
     if (lds4 <= 64 * 1024 && st->R >= 2048) {
-        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
+        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
                            per_wave);
     } else {
@@ -353,9 +372,9 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
                       depot_knn, lds1);
         if (lds1 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1, UPDATE>,
+            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1, UPDATE, D3>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
+        hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
                            t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
     }
     DGL_CHECK_LAUNCH(what);
@@ -373,8 +392,11 @@ extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, 
                   "idx_last_out, idx_depot_out, infeasible_out and tile_out must all be given or all be NULL");
     DGL_CHECK_ARG(!want || (knn >= 1 && depot_knn >= 1), "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
     if (!want) knn = depot_knn = 1;
-    return launch_cvrp_step<true>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                                  stream, "dgl_cvrp_step");
+    if (st->demand_in_distance)
+        return launch_cvrp_step<true, true>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                            tile_out, stream, "dgl_cvrp_step");
+    return launch_cvrp_step<true, false>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                         tile_out, stream, "dgl_cvrp_step");
 }
 
 extern "C" int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, int32_t depot_knn,
@@ -384,8 +406,11 @@ extern "C" int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, 
     DGL_CHECK_ARG(t >= 1 && t < st->N, "t=%d outside [1,N-1=%d]", t, st->N - 1);
     DGL_CHECK_ARG(idx_last_out && idx_depot_out && infeasible_out && tile_out, "NULL output");
     DGL_CHECK_ARG(knn >= 1 && depot_knn >= 1, "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
-    return launch_cvrp_step<false>(st, nullptr, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                                   stream, "dgl_cvrp_knn");
+    if (st->demand_in_distance)
+        return launch_cvrp_step<false, true>(st, nullptr, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                             tile_out, stream, "dgl_cvrp_knn");
+    return launch_cvrp_step<false, false>(st, nullptr, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                          tile_out, stream, "dgl_cvrp_knn");
 }
 
 extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream) {
@@ -393,7 +418,10 @@ extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float 
     DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
     DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
     dim3 grid(min((st->N + 256) / 256, 64), st->R);
-    hipLaunchKernelGGL(cvrp_state_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    if (st->demand_in_distance)
+        hipLaunchKernelGGL(cvrp_state_data_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    else
+        hipLaunchKernelGGL(cvrp_state_data_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
     DGL_CHECK_LAUNCH("dgl_cvrp_state_data");
     return DGL_OK;
 }

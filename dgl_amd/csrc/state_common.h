@@ -7,26 +7,46 @@
 // grid: (ceil(M / 256), B), block 256; thread t handles node i = 256*blockIdx.x + t and sums
 // d(i, j) over j = 0..M-1 in binary64 (rounded once at the end).  The instance's coordinates are
 // staged once per block in LDS (dynamic, 8*M bytes) and read back as broadcasts (every lane reads
-// the same j).  Also clears the visited bitmask.
-__device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, int M, int rows_per_instance,
+// the same j).  Also clears the visited bitmask.  z (may be NULL): a third coordinate per node
+// ([B][M]; the CVRP training reset measures distances over (x, y, demand), CVRP/CVRPEnv.py:519):
+// |p|^2 = (x^2 + y^2) + z^2 and the product chain gets one more FMA.
+__device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, const float *__restrict__ z, int M,
+                                               int rows_per_instance,
                                                float *__restrict__ avg, float *__restrict__ sd,
                                                uint64_t *__restrict__ visited) {
     extern __shared__ float lds_xy[];   // [M][2]
     const int b = blockIdx.y;
     const float *xyb = xy + (size_t)b * M * 2;
     for (int e = threadIdx.x; e < 2 * M; e += blockDim.x) lds_xy[e] = xyb[e];
+    float *lds_z = lds_xy + 2 * M;
+    if (z)
+        for (int e = threadIdx.x; e < M; e += blockDim.x) lds_z[e] = z[(size_t)b * M + e];
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) {
-        const float xi = lds_xy[2 * i], yi = lds_xy[2 * i + 1], ni = dgl_sqnorm(xi, yi);
+        const float xi = lds_xy[2 * i], yi = lds_xy[2 * i + 1];
         const float2 *pts = reinterpret_cast<const float2 *>(lds_xy);
         double s = 0.0, q = 0.0;
+        if (z == nullptr) {
+            const float ni = dgl_sqnorm(xi, yi);
 #pragma unroll 4
-        for (int j = 0; j < M; ++j) {
-            const float2 pj = pts[j];
-            const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
-            s += d;
-            q = fma(d, d, q);
+            for (int j = 0; j < M; ++j) {
+                const float2 pj = pts[j];
+                const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
+                s += d;
+                q = fma(d, d, q);
+            }
+        } else {
+            const float zi = lds_z[i], ni = __fadd_rn(dgl_sqnorm(xi, yi), __fmul_rn(zi, zi));
+#pragma unroll 4
+            for (int j = 0; j < M; ++j) {
+                const float2 pj = pts[j];
+                const float zj = lds_z[j], nj = __fadd_rn(dgl_sqnorm(pj.x, pj.y), __fmul_rn(zj, zj));
+                const float cross = __fmaf_rn(-2.0f * zi, zj, dgl_chain_cross(xi, yi, pj.x, pj.y));
+                const double d = (double)dgl_sqrt(dgl_chain_sq(cross, ni, nj));
+                s += d;
+                q = fma(d, d, q);
+            }
         }
         const double mean = s / M;
         const double var = q / M - mean * mean;

@@ -15,7 +15,7 @@
 // --------------------------------------------------------------------------- reset
 // grid: (ceil(N / 256), B), block 256 (see dgl_reset_rows in state_common.h)
 __global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
-    dgl_reset_rows(st.xy, st.N, st.rows_per_instance, st.avg, st.sd, st.visited);
+    dgl_reset_rows(st.xy, nullptr, st.N, st.rows_per_instance, st.avg, st.sd, st.visited);
 }
 
 // ---------------------------------------------------------------------------- step

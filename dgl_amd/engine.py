@@ -264,7 +264,11 @@ class CvrpEngine:
     """Compact CVRP state.  ``xy`` [B][N+1][2] (depot first), ``demand`` [B][N+1] (depot 0,
     already divided by the vehicle capacity)."""
 
-    def __init__(self, xy: torch.Tensor, demand: torch.Tensor, rows_per_instance: int, knn: int, depot_knn: int):
+    def __init__(self, xy: torch.Tensor, demand: torch.Tensor, rows_per_instance: int, knn: int, depot_knn: int,
+                 demand_in_distance: bool = False):
+        """``demand_in_distance``: distances over (x, y, demand), as the reference's training reset builds its
+        matrix (CVRP/CVRPEnv.py:519); the test / validation reset measures (x, y) only."""
+        self.demand_in_distance = bool(demand_in_distance)
         assert xy.is_cuda and xy.dtype == torch.float32 and xy.dim() == 3 and xy.shape[2] == 2
         assert demand.is_cuda and demand.dtype == torch.float32 and demand.shape == xy.shape[:2]
         self.lib = _lib.load()
@@ -333,7 +337,7 @@ class CvrpEngine:
                  flags=torch.zeros(R, N, dtype=torch.int8, device=dev))
         t["struct"] = _lib.CvrpState(self.B, N, self.rpi, R, ptr(self.xy), ptr(self.demand), ptr(t["avg"]),
                                      ptr(t["sd"]), ptr(t["capacity"]), ptr(t["visited"]), ptr(t["nodes"]),
-                                     ptr(t["flags"]))
+                                     ptr(t["flags"]), 1 if self.demand_in_distance else 0)
         return t
 
     @property

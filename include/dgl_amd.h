@@ -120,6 +120,8 @@ typedef struct {
     uint64_t *visited;         /* [R][ceil(M/64)] */
     int32_t *nodes;            /* [R][N] position -> customer */
     int8_t *flags;             /* [R][N] 1 = reached via the depot */
+    int32_t demand_in_distance; /* 0: distances over (x, y) (test/valid reset, CVRP/CVRPEnv.py:475);
+                                   1: over (x, y, demand) as reset('train') builds them (:519) */
 } dgl_cvrp_state_t;
 
 /* CVRPEnv.reset('test') (CVRP/CVRPEnv.py:456-482). */

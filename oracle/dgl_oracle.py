@@ -291,15 +291,17 @@ class CVRPOracle:
         self.knn = knn
         self.depot_knn = depot_knn
 
-    def reset(self, depot_xy: Tensor, node_xy: Tensor, demand: Tensor, rows_per_instance: int = 1) -> None:
-        """depot_xy [B,2]; node_xy [B,N,2]; demand [B,N] (already / capacity)."""
+    def reset(self, depot_xy: Tensor, node_xy: Tensor, demand: Tensor, rows_per_instance: int = 1,
+              train: bool = False) -> None:
+        """depot_xy [B,2]; node_xy [B,N,2]; demand [B,N] (already / capacity).  ``train``: the distance
+        matrix of reset('train') (CVRP/CVRPEnv.py:519), cdist over (x, y, demand)."""
         B, N = node_xy.shape[0], node_xy.shape[1]
         self.B, self.N, self.rpi = B, N, rows_per_instance
         self.R = B * rows_per_instance
         xy = torch.cat((depot_xy[:, None, :], node_xy), dim=1)
         dem = torch.cat((torch.zeros(B, 1), demand), dim=1)
         self.problems = torch.cat((xy, dem[:, :, None]), dim=2)
-        self.dis = torch.cdist(xy, xy, p=2).to(torch.float32)
+        self.dis = (torch.cdist(self.problems, self.problems, p=2) if train else torch.cdist(xy, xy, p=2)).to(torch.float32)
         self.xy = xy.repeat_interleave(rows_per_instance, 0)
         self.demand = dem.repeat_interleave(rows_per_instance, 0)
         self.capacity = torch.ones(self.R)
@@ -530,3 +532,28 @@ def train_forward_backward(oracle, teacher: Tensor):
     loss = -prob.type(torch.float64).log().mean()
     loss.backward()
     return prob.detach(), float(loss.detach())
+
+
+def cvrp_train_batch(oracle: "CVRPOracle", xy: Tensor, demand: Tensor, solution: Tensor, solution_flag: Tensor,
+                     lr: float = 1e-4, weight_decay: float = 1e-6, hook=None):
+    """CVRPTrainer._train_one_batch (CVRP/CVRPTrainer.py:232-282): xy [B,N+1,2] (depot first; the
+    coordinates reset('train') produced), demand [B,N], labels solution / solution_flag [B,N].
+    ``oracle.w`` must hold gradient-recording leaves; one torch Adam step per decode step.
+    Returns (probs [N-1][B], losses [N-1])."""
+    N = xy.shape[1] - 1
+    params = list(oracle.w.values())
+    opt = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+    act = solution + solution_flag * (N + 1)
+    oracle.reset(xy[:, 0], xy[:, 1:], demand, train=True)
+    oracle.step(act[:, 0].clone())
+    probs, losses = [], []
+    for t in range(1, N):
+        prob, loss = train_forward_backward(oracle, act[:, t])
+        if hook is not None:
+            hook(t, oracle)
+        opt.step()
+        probs.append(prob)
+        losses.append(loss)
+        with torch.no_grad():
+            oracle.step(act[:, t].clone())
+    return torch.stack(probs, 0), losses

@@ -171,3 +171,68 @@ def test_greedy_rollout_with_50_neighbours(device):
     # random-init weights have arg-max margins at rounding level, so only the first decisions are compared
     assert (tour[:, :3] == ref["tour"].numpy()[:, :3]).all()
     assert np.isfinite(length.cpu().numpy()).all()
+
+
+def test_cvrp_training_batch_matches_reference_golden(device):
+    """CVRPTrainer._train_one_batch on the device against the batch captured from the reference
+    (tests/golden/train_cvrp_n40_b4.npz): the training reset's (x, y, demand) distances, teacher-forced
+    decode, one Adam update per decode step."""
+    import os
+    from conftest import GOLDEN
+    from dgl_amd._lib import PROBLEM_CVRP
+    from dgl_amd.engine import CvrpEngine
+    from dgl_amd.train import PolicyTrainer
+    g = np.load(os.path.join(GOLDEN, "train_cvrp_n40_b4.npz"))
+    w0 = np.load(os.path.join(GOLDEN, "weights_cvrp_init789.npz"))
+    w = {k: torch.from_numpy(w0[k]) for k in w0.files}
+    knn, kd = int(g["meta/knn"]), int(g["meta/depot_knn"])
+    xy = torch.from_numpy(g["aug_xy"]).to(device)
+    dem = torch.from_numpy(g["problems"][:, :, 2]).to(device)
+    eng = CvrpEngine(xy, dem, 1, knn, kd, demand_in_distance=True)
+    tr = PolicyTrainer(w, PROBLEM_CVRP, device)
+    N = eng.N
+    sol, flag = torch.from_numpy(g["solution"]), torch.from_numpy(g["solution_flag"])
+    act = (sol + flag * (N + 1)).to(device=device, dtype=torch.int32)
+    eng.reset()
+    eng.step(act[:, 0].contiguous())
+    probs = []
+    for t in range(1, N):
+        tr.zero_grad()
+        prob = tr.forward_backward(eng, act[:, t].contiguous())
+        if t <= 3:
+            # (the last block's W2 bias gradient vanishes identically: tolerances are floored by the model's scale)
+            top = max(float(g[f"grad{t}/norm/{k}"]) for k in tr.keys)
+            for k, gv in tr.gradient_dict().items():
+                ref = float(g[f"grad{t}/norm/{k}"])
+                got = float(gv.double().norm())
+                assert abs(got - ref) <= 2e-3 * max(ref, 1e-3 * top), f"step {t} {k}: gradient norm {got} vs {ref}"
+                if f"grad{t}/full/{k}" in g:
+                    full = g[f"grad{t}/full/{k}"]
+                    np.testing.assert_allclose(gv.cpu().numpy(), full, rtol=5e-3, atol=2e-3 * np.abs(full).max() + 1e-6 * top)
+        tr.optimizer_step()
+        if t <= 3:
+            sd = tr.state_dict()
+            for k in tr.keys:
+                if f"param{t}/full/{k}" in g:
+                    # Adam's first updates are lr * g / (|g| + eps): where a gradient entry is rounding noise of the
+                    # size of eps the update is too, so a few entries may differ by a fraction of t * lr
+                    d = np.abs(sd[k].cpu().numpy() - g[f"param{t}/full/{k}"])
+                    noise_only = float(g[f"grad{t}/norm/{k}"]) < 1e-3 * top       # identically vanishing gradient
+                    assert d.max() < t * 1e-4 and (noise_only or np.quantile(d, 0.98) < 3e-6), (k, t, d.max())
+        probs.append(prob.cpu().numpy())
+        eng.step(act[:, t].contiguous())
+    probs = np.stack(probs, 0)
+    rel = np.abs(probs - g["prob"]) / g["prob"]
+    print(f"teacher probabilities over {N - 1} Adam steps: max relative difference {rel.max():.2e}, "
+          f"median {np.median(rel):.2e}")
+    loss = -np.log(probs.astype(np.float64)).mean(axis=1)
+    np.testing.assert_allclose(loss, g["loss"], rtol=2e-3, atol=2e-4)
+    assert np.median(rel) < 1e-4 and rel.max() < 2e-2
+    sd = tr.state_dict()
+    # the gradients of the two last biases vanish identically (softmax gradients sum to zero): Adam turns their
+    # rounding noise into steps of up to lr each, so those two tensors random-walk
+    noise_driven = ("decoder.Linear_final.bias", "decoder.layers.2.feedForward.W2.bias")
+    for k in tr.keys:
+        ref = float(g[f"final/norm/{k}"])
+        slack = (N * 1e-4 * np.sqrt(sd[k].numel())) if k in noise_driven else 0.0
+        assert abs(float(sd[k].double().norm()) - ref) <= 1e-3 * ref + slack, k

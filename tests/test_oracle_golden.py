@@ -103,3 +103,34 @@ def test_golden_feasibility_cvrp():
                     load = 0.0
                 load += float(dem[r // rpi, nodes[r, p] - 1])
                 assert load <= 1.0 + 1e-5
+
+
+def test_cvrp_training_batch_oracle_reproduces_reference():
+    """One batch of CVRPTrainer._train_one_batch captured from the reference (oracle/make_train_goldens.py):
+    teacher probabilities, losses, gradient and parameter checksums of the first Adam steps."""
+    from oracle.dgl_oracle import cvrp_train_batch, enable_grad
+    g = np.load(os.path.join(GOLDEN, "train_cvrp_n40_b4.npz"))
+    w0 = np.load(os.path.join(GOLDEN, "weights_cvrp_init789.npz"))
+    w = {k: torch.from_numpy(w0[k]) for k in w0.files}
+    orc = CVRPOracle(w, int(g["meta/knn"]), int(g["meta/depot_knn"]))
+    orc.w = enable_grad(w)
+    seen = {}
+
+    def hook(t, o):
+        if t <= 3:
+            seen[t] = {k: (float(v.grad.double().norm()), float(v.grad.double().sum()))
+                       for k, v in o.w.items() if v.grad is not None}
+
+    probs, losses = cvrp_train_batch(orc, torch.from_numpy(g["aug_xy"]), torch.from_numpy(g["problems"][:, 1:, 2]),
+                                     torch.from_numpy(g["solution"]), torch.from_numpy(g["solution_flag"]), hook=hook)
+    exact = str(g["meta/torch"]) == torch.__version__
+    if exact:
+        assert np.array_equal(probs.numpy(), g["prob"])
+    np.testing.assert_allclose(probs.numpy(), g["prob"], rtol=1e-4)
+    np.testing.assert_allclose(np.array(losses), g["loss"], rtol=1e-5)
+    for t in (1, 2, 3):
+        for k, (nrm, sm) in seen[t].items():
+            np.testing.assert_allclose(nrm, float(g[f"grad{t}/norm/{k}"]), rtol=1e-4, atol=1e-9)
+    for k, v in orc.w.items():
+        if f"final/norm/{k}" in g:
+            np.testing.assert_allclose(float(v.detach().double().norm()), float(g[f"final/norm/{k}"]), rtol=1e-6)
