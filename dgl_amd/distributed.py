@@ -40,3 +40,15 @@ def reduce_stats(sum_len: float, sum_gap: float, count: float, device=None) -> T
     t = torch.tensor([sum_len, sum_gap, count], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0]), float(t[1]), float(t[2])
+
+
+def all_reduce_gradients(flat: torch.Tensor) -> torch.Tensor:
+    """Sum of the flat gradient vector over the ranks, in place (identity when not distributed).
+    Every rank scales its loss by 1 / (rows of the GLOBAL batch), so the sum is the gradient of the
+    reference's loss.mean() over the whole batch (CVRP/CVRPTrainer.py:269-272); it goes between
+    backward and optimizer.step, once per decode step.  856 961 floats for CVRP: one small message,
+    latency-bound on xGMI."""
+    import torch.distributed as dist
+    if world()[1] > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat

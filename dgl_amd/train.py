@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import PROBLEM_TSP, check, ptr, stream_ptr
+from .distributed import all_reduce_gradients
 from .engine import general_workspace, weights_struct
 
 UNUSED = ("decoder.embedding_last_node_pos.", "decoder.k_1.")
@@ -80,8 +81,7 @@ class PolicyTrainer:
 
     def optimizer_step(self) -> None:
         """Gradient all-reduce (sum over ranks; the per-rank gradients already carry 1/global_rows) and Adam."""
-        if world_size() > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM)
+        all_reduce_gradients(self.grads)
         self.step_count += 1
         b1, b2 = self.betas
         check(self.lib.dgl_adam_step(ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),

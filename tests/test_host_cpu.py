@@ -92,3 +92,63 @@ def test_cvrp_instance_file_parser(tmp_path):
     depot, nodes, dem = read_cvrp_instances_from_file(str(p))
     assert depot.shape == (2, 2) and nodes.shape == (2, 3, 2) and dem.shape == (2, 3)
     np.testing.assert_allclose(dem.numpy(), [[0.2, 0.4, 0.1], [0.1, 0.2, 0.3]])
+
+
+def _grad_worker(rank, ws, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from dgl_amd.distributed import all_reduce_gradients, shard_range
+    from oracle.dgl_oracle import TSPOracle, enable_grad, random_weights
+    torch.set_num_threads(1)
+    B, N, knn = 6, 40, 10
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(B, N, 2, generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    w = random_weights("TSP", 7)
+    lo, hi = shard_range(B, rank, ws)
+    orc = TSPOracle(w, knn)
+    orc.w = enable_grad(w)
+    orc.reset(xy[lo:hi])
+    orc.step(start[lo:hi])
+    out_f = orc.forward()
+    teacher = orc.knn_indices()[:, 1]
+    prob = out_f["probs"][torch.arange(hi - lo), teacher]
+    loss = -(prob.double().log().sum() / B)                    # this rank's share of the global mean
+    loss.backward()
+    keys = [k for k, v in orc.w.items() if v.grad is not None]
+    flat = torch.cat([orc.w[k].grad.reshape(-1) for k in keys])
+    all_reduce_gradients(flat)
+    out[rank] = flat.numpy().copy()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """Per-rank gradients of (local sum of -log p) / (global rows), summed over the ranks, equal the
+    gradient of the reference's mean over the whole batch."""
+    import torch
+    import torch.multiprocessing as mp
+    from oracle.dgl_oracle import TSPOracle, enable_grad, random_weights, train_forward_backward
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    B, N, knn = 6, 40, 10
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(B, N, 2, generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    w = random_weights("TSP", 7)
+    orc = TSPOracle(w, knn)
+    orc.w = enable_grad(w)
+    orc.reset(xy)
+    orc.step(start)
+    train_forward_backward(orc, orc.knn_indices()[:, 1])
+    ref = torch.cat([v.grad.reshape(-1) for v in orc.w.values() if v.grad is not None]).numpy()
+    assert np.array_equal(out[0], out[1])
+    np.testing.assert_allclose(out[0], ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max())
