@@ -37,35 +37,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int k_lo = blockIdx.z * g.kchunk, k_hi = min(g.KK, k_lo + g.kchunk);
     const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
     f32x16 acc = zero16();
-    // staging map: whichever index is contiguous in memory runs fastest across threads
+    // staging map: whichever index is contiguous in memory runs fastest across threads; the next K-chunk is
+    // fetched into registers while the MFMAs of the current one run
     const bool a_k_fast = g.sak == 1, b_k_fast = g.sbk == 1;
+    int ai[4], ak[4], bj[4], bk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = tid + 256 * e;
+        if (a_k_fast) { ak[e] = o & 15; ai[e] = o >> 4; } else { ai[e] = o & 63; ak[e] = o >> 6; }
+        if (b_k_fast) { bk[e] = o & 15; bj[e] = o >> 4; } else { bj[e] = o & 63; bk[e] = o >> 6; }
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool av = (i0 + ai[e]) < g.I && (k0 + ak[e]) < k_hi;
+            const bool bv = (j0 + bj[e]) < g.J && (k0 + bk[e]) < k_hi;
+            ra[e] = av ? g.A[(long)(i0 + ai[e]) * g.sai + (long)(k0 + ak[e]) * g.sak] : 0.0f;
+            rb[e] = bv ? g.B[(long)(k0 + bk[e]) * g.sbk + (long)(j0 + bj[e]) * g.sbn] : 0.0f;
+        }
+    };
+    fetch(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int o = tid + 256 * e;
-            int ai, ak, bj, bk;
-            if (a_k_fast) { ak = o & 15; ai = o >> 4; } else { ai = o & 63; ak = o >> 6; }
-            if (b_k_fast) { bk = o & 15; bj = o >> 4; } else { bj = o & 63; bk = o >> 6; }
-            const bool av = (i0 + ai) < g.I && (k0 + ak) < k_hi;
-            const bool bv = (j0 + bj) < g.J && (k0 + bk) < k_hi;
-            As[ai][ak] = av ? g.A[(long)(i0 + ai) * g.sai + (long)(k0 + ak) * g.sak] : 0.0f;
-            Bs[bj][bk] = bv ? g.B[(long)(k0 + bk) * g.sbk + (long)(j0 + bj) * g.sbn] : 0.0f;
+            As[ai[e]][ak[e]] = ra[e];
+            Bs[bj[e]][bk[e]] = rb[e];
         }
         __syncthreads();
+        if (k0 + 16 < k_hi) fetch(k0 + 16);
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc = MFMA32(As[wi + q][2 * t + h], Bs[wj + q][2 * t + h], acc);
         __syncthreads();
     }
     const int j = j0 + wj + q;
     if (j >= g.J) return;
-    const float bj = (g.mode == 0 && g.bias) ? g.bias[j] : 0.0f;
+    const float bias_j = (g.mode == 0 && g.bias) ? g.bias[j] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (i >= g.I) continue;
         float *c = g.C + (long)i * g.ldc + j;
         if (g.mode == 0) {
-            float v = acc[r] + bj;
+            float v = acc[r] + bias_j;
             if (g.relu) v = fmaxf(v, 0.0f);
             if (g.add) v = g.add[(long)i * g.ldadd + j] + v;
             *c = v;
@@ -95,7 +109,7 @@ static void linear_bwd_x(hipStream_t s, const float *dY, int ldy, const float *W
 }
 // dW[N][K] += dY[M][N]^T X[M][K]   (atomics over chunks of M)
 static void linear_bwd_w(hipStream_t s, const float *dY, int ldy, const float *X, int ldx, float *dW, int M, int N, int K) {
-    GemmArgs g{dY, X, dW, nullptr, nullptr, N, K, M, 1, ldy, ldx, 1, K, 0, 2, 0, 2048};
+    GemmArgs g{dY, X, dW, nullptr, nullptr, N, K, M, 1, ldy, ldx, 1, K, 0, 2, 0, 512};
     launch_gemm(s, g);
 }
 
@@ -103,13 +117,13 @@ static void linear_bwd_w(hipStream_t s, const float *dY, int ldy, const float *X
 __global__ void colsum_kernel(const float *__restrict__ dY, int ld, int M, int N, float *__restrict__ db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
-    const int i_lo = blockIdx.y * 1024, i_hi = min(M, i_lo + 1024);
+    const int i_lo = blockIdx.y * 128, i_hi = min(M, i_lo + 128);
     float s = 0.0f;
     for (int i = i_lo; i < i_hi; ++i) s += dY[(long)i * ld + j];
     atomicAdd(db + j, s);
 }
 static void bias_bwd(hipStream_t s, const float *dY, int ld, int M, int N, float *db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, (M + 1023) / 1024), dim3(128), 0, s, dY, ld, M, N, db);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, (M + 127) / 128), dim3(128), 0, s, dY, ld, M, N, db);
 }
 
 // dH *= (H > 0)
@@ -493,7 +507,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         const float *Xin = X[l];
         if (l == 1) {
             // E keeps the encoder output; X[1] = E with re-embedded anchors
-            hipMemcpyAsync(E, X[1], MD * sizeof(float), hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(E, X[1], MD * sizeof(float), hipMemcpyDeviceToDevice, s);
             hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, X[1], n, anchor0, anchor1,
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0]);
         }

@@ -113,3 +113,21 @@ def train_one_batch_cvrp(trainer: PolicyTrainer, engine, solution: torch.Tensor,
     lp = torch.stack(logs, 1)
     # the reference's prob_list also holds the ones of the first step (log 1 = 0)
     return float(-(lp.sum() / (lp.numel() + lp.shape[0])))
+
+
+def train_one_batch_tsp(trainer: PolicyTrainer, engine, solution: torch.Tensor) -> float:
+    """TSPTrainer._train_one_batch (TSP/TSPTrainer.py:216-256): ``solution`` [R][N] node ids in visiting
+    order; the first node is given, every later one is a teacher-forced decision with its own Adam update."""
+    N = engine.N
+    act = solution.to(device=engine.device, dtype=torch.int32)
+    engine.reset()
+    engine.step(act[:, 0].contiguous())
+    logs = []
+    for t in range(1, N):
+        trainer.zero_grad()
+        prob = trainer.forward_backward(engine, act[:, t].contiguous())
+        trainer.optimizer_step()
+        logs.append(prob.double().log())
+        engine.step(act[:, t].contiguous())
+    lp = torch.stack(logs, 1)
+    return float(-(lp.sum() / (lp.numel() + lp.shape[0])))
