@@ -120,3 +120,47 @@ def test_dense_advance_synthetic(device):
         got = pk.cpu().numpy().astype(np.int64) * A + ac.cpu().numpy()
         assert np.array_equal(got, order), (G, beam, A, step)
         assert np.array_equal(sc_d.cpu().numpy(), exp_val)
+
+
+def test_tsp10000_beam_steps_follow_oracle(device):
+    """Large-n stress (TSP-10000, beam 4): the first beam steps against the oracle - kNN index sets
+    bit-exact, beam decisions identical where the scores are separated.  One wave per row with 40 KB of
+    keys in LDS; no [N][N] matrix on the device."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from oracle.dgl_oracle import TSPOracle, beam_advance, random_weights
+    N, beam, knn, steps = 10000, 4, 30, 6
+    g = torch.Generator().manual_seed(31)
+    xy = torch.rand(1, N, 2, generator=g)
+    w = random_weights("TSP", 8)
+    orc = TSPOracle(w, knn)
+    orc.reset(xy, rows_per_instance=beam)
+    start = torch.full((beam,), 4321, dtype=torch.long)
+    orc.step(start)
+    eng = TspEngine(xy.to(device), beam, knn)
+    pol = PackedPolicy(w, _lib.PROBLEM_TSP, device)
+    eng.reset()
+    eng.step(start.to(device=device, dtype=torch.int32))
+    scores_o = torch.zeros(1, beam)
+    scores = torch.zeros(1, beam, device=device)
+    pk, ac = torch.zeros(1, beam, dtype=torch.int32, device=device), torch.zeros(1, beam, dtype=torch.int32, device=device)
+    for s in range(steps):
+        out = orc.forward()
+        assert np.array_equal(eng.idx.cpu().numpy(), out["idx"].numpy()), f"kNN sets differ at step {s + 1}"
+        best, prev_k, action = beam_advance(torch.log(out["probs"]).view(1, beam, -1), scores_o, s + 1, beam, N)
+        eng.forward(pol)
+        sc = scores.clone()
+        eng.beam_advance(sc, beam, s + 1, pk, ac)
+        sep = float(np.abs(np.diff(best.numpy(), axis=1)).min()) > 1e-4
+        if sep:
+            assert np.array_equal(pk.cpu().numpy(), prev_k.numpy()) and np.array_equal(ac.cpu().numpy(), action.numpy())
+        np.testing.assert_allclose(sc.cpu().numpy(), best.numpy(), atol=5e-3)
+        scores_o = best
+        scores = best.to(device)
+        orc.permute_beams(prev_k, beam)
+        orc.step(action.view(-1))
+        eng.permute(prev_k.to(device=device, dtype=torch.int32).contiguous(), beam)
+        eng.step(action.view(-1).to(device=device, dtype=torch.int32).contiguous())
+    a, sd_ = eng.state["avg"].cpu().numpy(), eng.state["sd"].cpu().numpy()
+    np.testing.assert_allclose(a, orc.avg.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(sd_, orc.std.numpy(), rtol=2e-5)
