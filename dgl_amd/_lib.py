@@ -75,6 +75,7 @@ SIGNATURES = {
     "dgl_policy_general_workspace_floats": (c_int64, [c_int32, c_int32]),
     "dgl_policy_general": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p]),
+    "dgl_augment": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dgl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
     "dgl_policy_scatter_probs": (c_int32, [POINTER(PolicyIO), c_void_p, c_void_p, c_int32, c_void_p]),

@@ -216,9 +216,17 @@ class TspEngine:
               "dgl_tsp_state_data")
         return out
 
-    def tour_length(self) -> torch.Tensor:
-        check(self.lib.dgl_tsp_tour_length(ctypes.byref(self.state["struct"]), ptr(self.length), stream_ptr()),
-              "dgl_tsp_tour_length")
+    def tour_length(self, xy: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Closed-tour length of every row; ``xy`` [B][N][2]: measure on these coordinates instead of the
+        engine's own (aug_test evaluates on the original instance, TSP/TSPEnv.py:508-509)."""
+        st = self.state["struct"]
+        if xy is not None:
+            assert xy.shape == self.xy.shape and xy.is_cuda and xy.dtype == torch.float32
+            self._len_xy = xy.contiguous()                      # keep alive until the kernel has run
+            t = self.state
+            st = _lib.TspState(self.B, self.N, self.rpi, self.R, ptr(self._len_xy), ptr(t["avg"]), ptr(t["sd"]),
+                               ptr(t["visited"]), ptr(t["tour"]))
+        check(self.lib.dgl_tsp_tour_length(ctypes.byref(st), ptr(self.length), stream_ptr()), "dgl_tsp_tour_length")
         return self.length
 
     def greedy_rollout(self, policy: PackedPolicy, start: torch.Tensor) -> torch.Tensor:

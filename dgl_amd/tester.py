@@ -80,7 +80,12 @@ class _TesterBase:
         return torch.randperm(self.env.problem_size)[:self.env.pomo_size]       # TSP/TSPTester.py:165
 
     def _summarise(self, reward, beam_size):
-        view = reward.view(self.env.batch_size, beam_size * self.env.pomo_size)
+        """Best of the beams / multi-starts (and augmentations, TSP/TSPTester.py:183-188) of every instance."""
+        if self.env_params.get("test_mode") == "aug_test":
+            a = self.env.aug_size
+            view = reward.view(self.env.batch_size // a, beam_size * self.env.pomo_size * a)
+        else:
+            view = reward.view(self.env.batch_size, beam_size * self.env.pomo_size)
         shortest, index = torch.min(view, dim=1)
         return shortest, index
 
@@ -132,6 +137,8 @@ class TSPTester(_TesterBase):
         else:
             length = eng.beam_rollout(policy, sel, beam_size)
         env.selected_count = eng.t
+        if getattr(env, "_orig_xy", None) is not None:             # aug_test: lengths on the original coordinates
+            length = env._get_travel_distance()
         shortest, index = self._summarise(length, beam_size)
         self.last_tours = env.selected_node_list
         self.last_lengths = length

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import PROBLEM_TSP
+from .augment import mix_augment
 from .engine import PackedPolicy, TspEngine
 from .nn_layout import DecoderParams, EncoderParams
 
@@ -66,8 +67,9 @@ class TSPEnv:
             self.baseline_path = env_params.get("baseline_path", "")
             if env_params["test_mode"] == "pomo_test":
                 self.pomo_size = env_params["aug_size"]
-            elif env_params["test_mode"] == "aug_test":
-                raise NotImplementedError("aug_test (coordinate augmentation) is not part of this build yet")
+            elif env_params["test_mode"] == "aug_test":        # TSP/TSPEnv.py:60-62
+                self.aug_size = env_params["aug_size"]
+                self.pomo_size = 1
         else:
             self.pomo_size = env_params["pomo_size"]
         info = list(env_params.get("append_information", SHIPPED_INFO))
@@ -109,6 +111,9 @@ class TSPEnv:
             self.problems = get_random_problems(batch_size, problem_size)
         else:
             self.problems = self.raw_data_nodes[episode:episode + batch_size]
+            if self.env_params.get("test_mode") == "aug_test":      # TSP/TSPEnv.py:119-121
+                self.problems = self.problems.repeat_interleave(self.aug_size, dim=0)
+                self.batch_size = self.batch_size * self.aug_size
         self.beam_size = beam_size
         self.solution = None
         self.solution_len = None
@@ -121,6 +126,11 @@ class TSPEnv:
         self.selected_count = 0
         nb = self.batch_size if mode == "test" else self.step_size
         xy = self.problems[self.start_idx:self.start_idx + nb].to(self.device, torch.float32).contiguous()
+        self._orig_xy = None
+        if mode == "test" and self.env_params.get("test_mode") == "aug_test":
+            # run_aug("mix", ...) on the repeated instances (TSP/TSPEnv.py:222-224); rewards use the originals
+            self._orig_xy = xy
+            xy = mix_augment(xy)
         self.engine = TspEngine(xy, self.pomo_size * self.beam_size, self.knn)
         self.engine.reset()
         self.step_state = Step_State(self.engine)
@@ -159,7 +169,7 @@ class TSPEnv:
         return self.step_state, reward, done
 
     def _get_travel_distance(self, instances=None):
-        return self.engine.tour_length().clone()
+        return self.engine.tour_length(self._orig_xy).clone()
 
 
 class TSPModel(nn.Module):

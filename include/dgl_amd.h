@@ -265,6 +265,15 @@ DGL_API int dgl_adam_step(float *params, const float *grads, float *exp_avg, flo
                           int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                           float grad_scale, dgl_stream_t stream);
 
+/* ----------------------------------------------------------------- augmentation
+ * mix_aug of the reference (utils/utils.py:790-878, used by reset('test') in aug_test mode,
+ * TSP/TSPEnv.py:222-224, CVRP/CVRPEnv.py:462-467, and by reset('train')): instance b is copied
+ * (kind 0), rotated (kind 1, cos_sin[b] = cos t, sin t) or reflected (kind 2, cos_sin[b] = cos 2t,
+ * sin 2t), shifted by +10 and rescaled to the unit square by its larger extent.  xy, xy_out
+ * [B][M][2]; the host draws the angles (the reference's torch.rand stream). */
+DGL_API int dgl_augment(const float *xy, int32_t B, int32_t M, const float *cos_sin, const int32_t *kind,
+                        float *xy_out, dgl_stream_t stream);
+
 /* ----------------------------------------------------------------------- beam
  * Beamsearch.advance (utils/beamsearch.py:52-131) on dense log-probabilities:
  * log_prob [G][beam][A]; scores [G][beam] in/out; step = current_step (>= 1; at step 1

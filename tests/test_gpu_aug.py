@@ -1,0 +1,65 @@
+"""aug_test protocol (coordinate augmentation, best-of-augmentation on the original coordinates)
+against the vectors captured from the reference (oracle/make_aug_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, "aug_tsp_n50_b3_a4.npz"))
+
+
+def test_mix_augment_reproduces_reference_coordinates(device):
+    from dgl_amd.augment import mix_augment
+    g = _golden()
+    aug = int(g["meta/aug"])
+    xy = torch.from_numpy(g["xy"]).repeat_interleave(aug, dim=0).to(device)
+    torch.manual_seed(int(g["meta/seed"]))
+    out = mix_augment(xy).cpu().numpy()
+    same_torch = str(g["meta/torch"]) == torch.__version__
+    if same_torch:                       # same torch.rand / cos / sin: the kernel's arithmetic is exact
+        assert np.array_equal(out, g["aug_xy"])
+    np.testing.assert_allclose(out, g["aug_xy"], rtol=0, atol=2e-6)
+    assert np.array_equal(out[0], g["xy"][0])           # only the first row of the batch stays as it is
+
+
+def test_aug_test_env_and_tester_reduction(device):
+    """TSPEnv in aug_test mode with the reference's loop: same tours, rewards on the original coordinates,
+    best-of-augmentation per instance."""
+    from dgl_amd import TSPEnv, TSPModel
+    from dgl_amd.tester import TSPTester
+    from dgl_amd.weights import load_checkpoint
+    g = _golden()
+    aug, knn = int(g["meta/aug"]), int(g["meta/knn"])
+    B, N = g["xy"].shape[0], g["xy"].shape[1]
+    info = [True, True, True, False, True, True, False, False, False, False, False]
+    model_params = dict(mode="test", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3, qkv_dim=16,
+                        head_num=8, ff_hidden_dim=512, append_information=info)
+    tester = TSPTester(env_params=dict(mode="test", test_mode="aug_test", aug_size=aug, append_information=info,
+                                       data_path="", aggregation_nums=50, pomo_size=1),
+                       model_params=model_params,
+                       tester_params=dict(use_cuda=True, cuda_device_num=0, knn=knn, beam_size=1, test_batch_size=B,
+                                          problem_size=N, test_episodes=B, test_episodes_all=B,
+                                          model_load={"enable": False}))
+    tester.model.load_state_dict(load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt")))
+    env = tester.env
+    env.raw_data_nodes = torch.from_numpy(g["xy"])
+    env.load_problems(0, B, N, 1)
+    env.start_idx, env.step_size = 0, B
+    assert env.batch_size == B * aug
+    torch.manual_seed(int(g["meta/seed"]))
+    shortest = tester.fast_rollout(1, start=torch.from_numpy(g["start"]))
+    tours = tester.last_tours.cpu().numpy()
+    same = (tours == g["tour"]).all(axis=1).mean()
+    print(f"aug_test: {same:.2f} of the {B * aug} augmented rollouts identical; best-of-aug {shortest.cpu().numpy()} "
+          f"vs {g['shortest']}")
+    assert same >= 0.9
+    np.testing.assert_allclose(tester.last_lengths.cpu().numpy()[(tours == g["tour"]).all(axis=1)],
+                               g["reward"][(tours == g["tour"]).all(axis=1)], rtol=2e-6)
+    np.testing.assert_allclose(shortest.cpu().numpy(), g["shortest"], rtol=2e-4)
