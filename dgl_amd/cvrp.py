@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import PROBLEM_CVRP
+from .augment import mix_augment
 from .engine import CvrpEngine, PackedPolicy
 from .nn_layout import DecoderParams, EncoderParams
 
@@ -93,7 +94,8 @@ class CVRPEnv:
             if env_params["test_mode"] == "pomo_test":
                 self.pomo_size = env_params["aug_size"]
             elif env_params["test_mode"] == "aug_test":
-                raise NotImplementedError("aug_test (coordinate augmentation) is not part of this build yet")
+                self.aug_size = env_params["aug_size"]
+                self.pomo_size = 1
         else:
             self.pomo_size = env_params["pomo_size"]
         info = list(env_params.get("append_information", SHIPPED_INFO))
@@ -134,9 +136,16 @@ class CVRPEnv:
             node_demand = self.raw_node_demand[episode:episode + batch_size]
             self.depot_node_xy = torch.cat((depot_xy[:, None, :], node_xy), dim=1)
         self.depot_node_demand = torch.cat((torch.zeros(size=(batch_size, 1)), node_demand), dim=1)
+        if self._aug_test():
+            self.depot_node_xy = self.depot_node_xy.repeat_interleave(self.aug_size, dim=0)
+            self.depot_node_demand = self.depot_node_demand.repeat_interleave(self.aug_size, dim=0)
+            self.batch_size = batch_size * self.aug_size
         self.problems = torch.cat((self.depot_node_xy, self.depot_node_demand[:, :, None]), dim=2)
         self.solution = None
         self.solution_len = None
+
+    def _aug_test(self) -> bool:
+        return self.mode == "test" and self.env_params.get("test_mode") == "aug_test"
 
     def reset(self, mode):
         if mode not in ("test", "valid"):
@@ -147,6 +156,10 @@ class CVRPEnv:
         sl = slice(self.start_idx, self.start_idx + nb)
         xy = self.depot_node_xy[sl].to(self.device, torch.float32).contiguous()
         dem = self.depot_node_demand[sl].to(self.device, torch.float32).contiguous()
+        self._orig_xy = None
+        if self._aug_test():                      # CVRP/CVRPEnv.py:462-467: decide on augmented coordinates
+            self._orig_xy = xy
+            xy = mix_augment(xy)
         self.engine = CvrpEngine(xy, dem, self.pomo_size * self.beam_size, self.knn, self.depot_knn)
         self.engine.reset()
         self.step_state = Step_State(self.engine)
@@ -183,11 +196,12 @@ class CVRPEnv:
         self.selected_count += 1
         e.step(act)
         done = self.selected_count == self.problem_size
-        reward = e.route_length().clone() if done else (None, None)
+        reward = self.cal_length() if done else (None, None)
         return self.step_state, reward, done
 
     def cal_length(self, problems=None, order_node=None, order_flag=None):
-        return self.engine.route_length().clone()
+        """Route length of the engine's routes; in aug_test on the original coordinates (CVRP/CVRPEnv.py:864-865)."""
+        return self.engine.route_length(self._orig_xy).clone()
 
 
 class CVRPModel(nn.Module):

@@ -409,8 +409,18 @@ class CvrpEngine:
               "dgl_cvrp_state_data")
         return out
 
-    def route_length(self) -> torch.Tensor:
-        check(self.lib.dgl_cvrp_route_length(ctypes.byref(self.state["struct"]), ptr(self.length), stream_ptr()),
+    def route_length(self, xy: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Route length of every row; ``xy`` [B][N+1][2]: measure on these coordinates instead of the engine's
+        own (aug_test evaluates on the original instance, CVRP/CVRPEnv.py:864-865)."""
+        st = self.state["struct"]
+        if xy is not None:
+            assert xy.shape == self.xy.shape and xy.is_cuda and xy.dtype == torch.float32
+            self._len_xy = xy.contiguous()                      # keep alive until the kernel has run
+            t = self.state
+            st = _lib.CvrpState(self.B, self.N, self.rpi, self.R, ptr(self._len_xy), ptr(self.demand), ptr(t["avg"]),
+                                ptr(t["sd"]), ptr(t["capacity"]), ptr(t["visited"]), ptr(t["nodes"]),
+                                ptr(t["flags"]), 0)
+        check(self.lib.dgl_cvrp_route_length(ctypes.byref(st), ptr(self.length), stream_ptr()),
               "dgl_cvrp_route_length")
         return self.length
 

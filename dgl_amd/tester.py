@@ -224,6 +224,8 @@ class CVRPTester(_TesterBase):
         policy = model.packed(self.device)
         length = eng.greedy_rollout(policy, sel) if beam_size == 1 else eng.beam_rollout(policy, sel, beam_size)
         env.selected_count = eng.t
+        if getattr(env, "_orig_xy", None) is not None:             # aug_test: lengths on the original coordinates
+            length = env.cal_length()
         shortest, index = self._summarise(length, beam_size)
         self.last_tours = env.selected_node_list
         self.last_flags = env.step_state.selected_flag

@@ -63,3 +63,45 @@ def test_aug_test_env_and_tester_reduction(device):
     np.testing.assert_allclose(tester.last_lengths.cpu().numpy()[(tours == g["tour"]).all(axis=1)],
                                g["reward"][(tours == g["tour"]).all(axis=1)], rtol=2e-6)
     np.testing.assert_allclose(shortest.cpu().numpy(), g["shortest"], rtol=2e-4)
+
+
+def test_cvrp_aug_test_env_and_tester_reduction(device):
+    """CVRPEnv in aug_test mode: reference-protocol loop and device-resident rollout against the reference's run."""
+    from dgl_amd.tester import CVRPTester
+    from dgl_amd.weights import load_checkpoint
+    g = np.load(os.path.join(GOLDEN, "aug_cvrp_n40_b3_a4.npz"))
+    aug, knn, kd = int(g["meta/aug"]), int(g["meta/knn"]), int(g["meta/depot_knn"])
+    B, N = g["node_xy"].shape[0], g["node_xy"].shape[1]
+    info = [True, True, True, False, True, True, False, False, False, False, False, False, False]
+    model_params = dict(mode="test", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3, qkv_dim=16,
+                        head_num=8, ff_hidden_dim=512, append_information=info)
+    tester = CVRPTester(env_params=dict(mode="test", test_mode="aug_test", aug_size=aug, append_information=info,
+                                        data_path="", aggregation_nums=10, pomo_size=1),
+                        model_params=model_params,
+                        tester_params=dict(use_cuda=True, cuda_device_num=0, knn=knn, depot_knn=kd, beam_size=1,
+                                           test_batch_size=B, problem_size=N, test_episodes=B, test_episodes_all=B,
+                                           model_load={"enable": False}))
+    tester.model.load_state_dict(load_checkpoint(os.path.join(GOLDEN, "ckpt_cvrp_nn.pt")))
+    env = tester.env
+    env.raw_depot_node_xy = torch.from_numpy(g["depot_xy"])
+    env.raw_node_xy = torch.from_numpy(g["node_xy"])
+    env.raw_node_demand = torch.from_numpy(g["demand"])
+    env.problem_size = N
+    env.load_problems(0, B, N)
+    env.start_idx, env.step_size = 0, B
+    assert env.batch_size == B * aug
+    for protocol in ("fast", "reference"):
+        torch.manual_seed(int(g["meta/seed"]))
+        if protocol == "fast":
+            shortest = tester.fast_rollout(1, start=torch.from_numpy(g["start"]))
+        else:
+            tester.beamsearch_tour_nodes_shortest(1, B, N + 1, start=torch.from_numpy(g["start"]))
+            shortest, _ = tester._summarise(tester.last_lengths, 1)
+        np.testing.assert_allclose(env.engine.xy.cpu().numpy(), g["aug_xy"], rtol=0, atol=2e-6)
+        nodes, flags = tester.last_tours.cpu().numpy(), tester.last_flags.cpu().numpy()
+        same = ((nodes == g["nodes"]) & (flags == g["flags"])).all(axis=1)
+        print(f"cvrp aug_test ({protocol}): {same.mean():.2f} of the {B * aug} augmented rollouts identical; best-of-aug "
+              f"{shortest.cpu().numpy()} vs {g['shortest']}")
+        assert same.mean() >= 0.9
+        np.testing.assert_allclose(tester.last_lengths.cpu().numpy()[same], g["reward"][same], rtol=2e-6)
+        np.testing.assert_allclose(shortest.cpu().numpy(), g["shortest"], rtol=2e-4)
