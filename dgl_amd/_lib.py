@@ -76,6 +76,10 @@ SIGNATURES = {
     "dgl_policy_general": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p]),
     "dgl_augment": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dgl_tsp_nearest_neighbour": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "dgl_cvrp_nearest_neighbour": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "dgl_cvrp_solution_augment": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
     "dgl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
     "dgl_policy_scatter_probs": (c_int32, [POINTER(PolicyIO), c_void_p, c_void_p, c_int32, c_void_p]),

@@ -8,7 +8,8 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ._lib import PROBLEM_CVRP
+from . import _lib
+from ._lib import PROBLEM_CVRP, check, ptr, stream_ptr
 from .augment import mix_augment
 from .engine import CvrpEngine, PackedPolicy
 from .nn_layout import DecoderParams, EncoderParams
@@ -144,23 +145,103 @@ class CVRPEnv:
         self.solution = None
         self.solution_len = None
 
+    # ---- self-improvement labels (training) ------------------------------------------------
+    def _device_instances(self, sl=slice(None)):
+        xy = self.depot_node_xy[sl].to(self.device, torch.float32).contiguous()
+        dem = self.depot_node_demand[sl].to(self.device, torch.float32).contiguous()
+        return xy, dem
+
+    def _label_length(self, xy, dem, nodes, flags) -> torch.Tensor:
+        """cal_length (CVRP/CVRPEnv.py:951-993) of labels held outside an engine."""
+        eng = CvrpEngine(xy, dem, 1, self.knn, self.depot_knn)
+        eng.state["nodes"].copy_(nodes.to(torch.int32))
+        eng.state["flags"].copy_(flags.to(torch.int8))
+        return eng.route_length().clone()
+
+    def greedy_search(self):
+        """Nearest-neighbour labels for the whole batch (CVRP/CVRPEnv.py:340-409)."""
+        lib = _lib.load()
+        xy, dem = self._device_instances()
+        B, N = self.batch_size, self.problem_size
+        nodes = torch.empty(B, N, dtype=torch.int32, device=self.device)
+        flags = torch.empty(B, N, dtype=torch.int8, device=self.device)
+        check(lib.dgl_cvrp_nearest_neighbour(ptr(xy), ptr(dem), B, N, ptr(nodes), ptr(flags), stream_ptr()),
+              "dgl_cvrp_nearest_neighbour")
+        self.solution = nodes.to(torch.int64)
+        self.solution_flag = flags.to(torch.int64)
+        self.solution_len = self._label_length(xy, dem, nodes, flags)
+        return self.solution_len.mean().item()
+
+    def random_replace(self, random_index=None, replacement=None):
+        """Fresh instances for ``replace_size`` random slots; their labels are outdated until the next
+        rollout beats the infinite length (CVRP/CVRPEnv.py:298-323).  Same host RNG calls as the reference
+        unless the slots and their new instances (``replacement`` [r][N+1][3]) are given."""
+        if random_index is None:
+            random_index = torch.randperm(self.batch_size)[:self.replace_size]
+            depot_xy, node_xy, node_demand = get_random_problems(self.replace_size, self.problem_size)
+            new_xy = torch.cat((depot_xy, node_xy), dim=1)
+            new_demand = torch.cat((torch.zeros(size=(self.replace_size, 1)), node_demand), dim=1)
+        else:
+            new_xy, new_demand = replacement[:, :, :2], replacement[:, :, 2]
+        self.depot_node_xy[random_index] = new_xy
+        self.depot_node_demand[random_index] = new_demand
+        self.problems = torch.cat((self.depot_node_xy, self.depot_node_demand[:, :, None]), dim=2)
+        self.solution_len[random_index.to(self.device)] = float("inf")
+        return random_index
+
+    def draw_label_augmentation(self):
+        """The reference's draws for data_augmentation, in its order on the host generator: per instance
+        one torch.rand(1) per sub-route but the last, then randint(0, S) (CVRP/CVRPEnv.py:329-335)."""
+        counts = self.solution_flag.sum(dim=1).tolist()
+        B, N = self.solution_flag.shape
+        flip = torch.zeros(B, N, dtype=torch.uint8)
+        shift = torch.zeros(B, dtype=torch.int32)
+        for i, S in enumerate(counts):
+            for j in range(1, int(S)):
+                if torch.rand(1) > 0.5:
+                    flip[i, j] = 1
+            shift[i] = torch.randint(0, int(S), (1,))[0].item()
+        return flip, shift
+
+    def data_augmentation(self, flip=None, shift=None):
+        """Sub-route reversals and rotation of every label (CVRP/CVRPEnv.py:325-338); ``flip`` [B][N] and
+        ``shift`` [B] default to draw_label_augmentation()."""
+        if flip is None or shift is None:
+            flip, shift = self.draw_label_augmentation()
+        lib = _lib.load()
+        B, N = self.solution.shape
+        nodes = self.solution.to(torch.int32).contiguous()
+        flags = self.solution_flag.to(torch.int8).contiguous()
+        flip = flip.to(device=self.device, dtype=torch.uint8).contiguous()
+        shift = shift.to(device=self.device, dtype=torch.int32).contiguous()
+        assert flip.shape == (B, N) and shift.shape == (B,) and int(shift.min()) >= 0
+        out_n, out_f = torch.empty_like(nodes), torch.empty_like(flags)
+        check(lib.dgl_cvrp_solution_augment(ptr(nodes), ptr(flags), B, N, ptr(flip), ptr(shift), ptr(out_n), ptr(out_f),
+                                            stream_ptr()), "dgl_cvrp_solution_augment")
+        self.solution = out_n.to(torch.int64)
+        self.solution_flag = out_f.to(torch.int64)
+
     def _aug_test(self) -> bool:
         return self.mode == "test" and self.env_params.get("test_mode") == "aug_test"
 
     def reset(self, mode):
-        if mode not in ("test", "valid"):
-            raise NotImplementedError("the training reset (augmented coordinates) is not part of this build yet")
+        if mode not in ("test", "valid", "train"):
+            raise ValueError(f"unknown mode {mode!r}")
         self.mode = mode
         self.selected_count = 0
-        nb = self.batch_size if mode == "test" else self.step_size
-        sl = slice(self.start_idx, self.start_idx + nb)
-        xy = self.depot_node_xy[sl].to(self.device, torch.float32).contiguous()
-        dem = self.depot_node_demand[sl].to(self.device, torch.float32).contiguous()
         self._orig_xy = None
-        if self._aug_test():                      # CVRP/CVRPEnv.py:462-467: decide on augmented coordinates
-            self._orig_xy = xy
-            xy = mix_augment(xy)
-        self.engine = CvrpEngine(xy, dem, self.pomo_size * self.beam_size, self.knn, self.depot_knn)
+        if mode == "train":
+            # CVRP/CVRPEnv.py:508-524: whole batch, one row per instance, mix-augmented coordinates,
+            # distance matrix over (x, y, demand)
+            xy, dem = self._device_instances()
+            self.engine = CvrpEngine(mix_augment(xy), dem, 1, self.knn, self.depot_knn, demand_in_distance=True)
+        else:
+            nb = self.batch_size if mode == "test" else self.step_size
+            xy, dem = self._device_instances(slice(self.start_idx, self.start_idx + nb))
+            if self._aug_test():                      # CVRP/CVRPEnv.py:462-467: decide on augmented coordinates
+                self._orig_xy = xy
+                xy = mix_augment(xy)
+            self.engine = CvrpEngine(xy, dem, self.pomo_size * self.beam_size, self.knn, self.depot_knn)
         self.engine.reset()
         self.step_state = Step_State(self.engine)
         self._permuted_at = -1
@@ -231,7 +312,8 @@ class CVRPModel(nn.Module):
     def forward(self, state, selected_node_list, solution, solution_flag, knn, current_step, depot_knn_nums,
                 selected_flag=None):
         if self.mode == "train":
-            raise NotImplementedError("the teacher-forced training step is not part of this build yet")
+            raise NotImplementedError("the teacher-forced step runs through dgl_amd.train.PolicyTrainer.forward_backward "
+                                      "(gradients live in its flat vector, not in autograd)")
         eng: CvrpEngine = state.engine
         if knn + depot_knn_nums + 2 > 32:
             raise NotImplementedError("more than 32 tokens per row (knn + depot_knn + 2) is not supported yet")

@@ -57,6 +57,47 @@ class PolicyTrainer:
             out[k] = (self.views[k] if k in self.views else self.unused[k]).detach().clone()
         return out
 
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        for k in self.order:
+            v = state_dict[k].to(device=self.device, dtype=torch.float32)
+            (self.views[k] if k in self.views else self.unused[k]).copy_(v)
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.Adam's state_dict layout over the parameters in checkpoint order (the trainers save
+        it as 'optimizer_state_dict', CVRP/CVRPTrainer.py:128-135): parameters that never received a
+        gradient have no state entry."""
+        state, off = {}, 0
+        index = {k: i for i, k in enumerate(self.order)}
+        for k in self.keys:
+            n = self.views[k].numel()
+            if self.step_count > 0:
+                state[index[k]] = {"step": torch.tensor(float(self.step_count)),
+                                   "exp_avg": self.exp_avg[off:off + n].view_as(self.views[k]).clone(),
+                                   "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(self.views[k]).clone()}
+            off += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        group = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        self.weight_decay = group["weight_decay"]
+        index = {k: i for i, k in enumerate(self.order)}
+        off, steps = 0, set()
+        for k in self.keys:
+            n = self.views[k].numel()
+            st = sd["state"].get(index[k])
+            if st is not None:
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            off += n
+        if len(steps) > 1:
+            raise ValueError("parameters with different Adam step counts are not supported")
+        self.step_count = steps.pop() if steps else 0
+
     def gradient_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.grad_views.items()}
 
@@ -111,6 +152,7 @@ def train_one_batch_cvrp(trainer: PolicyTrainer, engine, solution: torch.Tensor,
         logs.append(prob.double().log())
         engine.step(act[:, t].contiguous())
     lp = torch.stack(logs, 1)
+    trainer.last_log_probs = lp
     # the reference's prob_list also holds the ones of the first step (log 1 = 0)
     return float(-(lp.sum() / (lp.numel() + lp.shape[0])))
 
@@ -130,4 +172,5 @@ def train_one_batch_tsp(trainer: PolicyTrainer, engine, solution: torch.Tensor) 
         logs.append(prob.double().log())
         engine.step(act[:, t].contiguous())
     lp = torch.stack(logs, 1)
+    trainer.last_log_probs = lp
     return float(-(lp.sum() / (lp.numel() + lp.shape[0])))

@@ -18,7 +18,8 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ._lib import PROBLEM_TSP
+from . import _lib
+from ._lib import PROBLEM_TSP, check, ptr, stream_ptr
 from .augment import mix_augment
 from .engine import PackedPolicy, TspEngine
 from .nn_layout import DecoderParams, EncoderParams
@@ -118,20 +119,48 @@ class TSPEnv:
         self.solution = None
         self.solution_len = None
 
+    # ---- self-improvement labels (training) -------------------------------------------
+    def greedy_search(self):
+        """Nearest-neighbour labels from node 0 for the whole batch (TSP/TSPEnv.py:140-169)."""
+        lib = _lib.load()
+        xy = self.problems.to(self.device, torch.float32).contiguous()
+        B, N = self.batch_size, self.problem_size
+        sol = torch.empty(B, N, dtype=torch.int32, device=self.device)
+        length = torch.empty(B, dtype=torch.float32, device=self.device)
+        check(lib.dgl_tsp_nearest_neighbour(ptr(xy), B, N, ptr(sol), ptr(length), stream_ptr()),
+              "dgl_tsp_nearest_neighbour")
+        self.solution = sol.to(torch.int64)
+        self.solution_len = length
+        return self.solution_len.mean().item()
+
+    def random_replace(self, random_index=None, replacement=None):
+        """Fresh instances for ``replace_size`` random slots (TSP/TSPEnv.py:130-137); same host RNG calls as
+        the reference unless the slots and their new instances (``replacement`` [r][N][2]) are given."""
+        if random_index is None:
+            random_index = torch.randperm(self.batch_size)[:self.replace_size]
+            replacement = get_random_problems(self.replace_size, self.problem_size)
+        self.problems[random_index] = replacement
+        self.solution_len[random_index.to(self.device)] = float("inf")
+        return random_index
+
     # ---- episode --------------------------------------------------------------------
     def reset(self, mode):
-        if mode not in ("test", "valid"):
-            raise NotImplementedError("the training reset (augmented coordinates) is not part of this build yet")
+        if mode not in ("test", "valid", "train"):
+            raise ValueError(f"unknown mode {mode!r}")
         self.mode = mode
         self.selected_count = 0
-        nb = self.batch_size if mode == "test" else self.step_size
-        xy = self.problems[self.start_idx:self.start_idx + nb].to(self.device, torch.float32).contiguous()
         self._orig_xy = None
-        if mode == "test" and self.env_params.get("test_mode") == "aug_test":
-            # run_aug("mix", ...) on the repeated instances (TSP/TSPEnv.py:222-224); rewards use the originals
-            self._orig_xy = xy
-            xy = mix_augment(xy)
-        self.engine = TspEngine(xy, self.pomo_size * self.beam_size, self.knn)
+        if mode == "train":                 # TSP/TSPEnv.py:255-266: whole batch, one row per instance, augmented
+            xy = mix_augment(self.problems.to(self.device, torch.float32).contiguous())
+            self.engine = TspEngine(xy, 1, self.knn)
+        else:
+            nb = self.batch_size if mode == "test" else self.step_size
+            xy = self.problems[self.start_idx:self.start_idx + nb].to(self.device, torch.float32).contiguous()
+            if mode == "test" and self.env_params.get("test_mode") == "aug_test":
+                # run_aug("mix", ...) on the repeated instances (TSP/TSPEnv.py:222-224); rewards use the originals
+                self._orig_xy = xy
+                xy = mix_augment(xy)
+            self.engine = TspEngine(xy, self.pomo_size * self.beam_size, self.knn)
         self.engine.reset()
         self.step_state = Step_State(self.engine)
         self._permuted_at = -1
@@ -200,7 +229,8 @@ class TSPModel(nn.Module):
 
     def forward(self, state, selected_node_list, solution, knn, current_step):
         if self.mode == "train":
-            raise NotImplementedError("the teacher-forced training step is not part of this build yet")
+            raise NotImplementedError("the teacher-forced step runs through dgl_amd.train.PolicyTrainer.forward_backward "
+                                      "(gradients live in its flat vector, not in autograd)")
         eng: TspEngine = state.engine
         eng.set_knn(knn)
         eng.ensure_neighbourhood()

@@ -274,6 +274,28 @@ DGL_API int dgl_adam_step(float *params, const float *grads, float *exp_avg, flo
 DGL_API int dgl_augment(const float *xy, int32_t B, int32_t M, const float *cos_sin, const int32_t *kind,
                         float *xy_out, dgl_stream_t stream);
 
+/* ---------------------------------------------------------- self-improvement labels
+ * Nearest-neighbour construction the trainers start from.  TSP (TSPEnv.greedy_search,
+ * TSP/TSPEnv.py:140-169): from node 0 always to the nearest unvisited node by the entries of the
+ * reference's cdist matrix (row = current node; equal distances go to the lower index);
+ * solution [B][N] int32, length [B] = sum of those entries around the closed tour.
+ * CVRP (CVRPEnv.greedy_search, CVRP/CVRPEnv.py:340-409): from the depot to the nearest unvisited
+ * customer; a move goes via the depot (flag 1, capacity 1 - demand) when capacity + 1e-6 < demand,
+ * the first move always does.  xy [B][N+1][2], demand [B][N+1]; nodes [B][N] int32, flags [B][N]
+ * int8 (the length follows from dgl_cvrp_route_length on a state whose nodes/flags point here). */
+DGL_API int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, int32_t *solution, float *length,
+                                      dgl_stream_t stream);
+DGL_API int dgl_cvrp_nearest_neighbour(const float *xy, const float *demand, int32_t B, int32_t N, int32_t *nodes,
+                                       int8_t *flags, dgl_stream_t stream);
+/* CVRPEnv.data_augmentation (CVRP/CVRPEnv.py:325-338) with the random draws as inputs: sub-route s
+ * (1-based, from the s-th set flag to the next) is reversed when flip[b][s] != 0 for s = 1..S-1
+ * (the reference draws torch.rand(1) > 0.5 per sub-route; the last one is never reversed), then
+ * label and flags are rotated to start at sub-route (shift[b] mod S) (0-based; the reference draws
+ * randint(0, S)).  flip [B][N] uint8, shift [B] int32 >= 0; not in place. */
+DGL_API int dgl_cvrp_solution_augment(const int32_t *nodes, const int8_t *flags, int32_t B, int32_t N,
+                                      const uint8_t *flip, const int32_t *shift, int32_t *nodes_out,
+                                      int8_t *flags_out, dgl_stream_t stream);
+
 /* ----------------------------------------------------------------------- beam
  * Beamsearch.advance (utils/beamsearch.py:52-131) on dense log-probabilities:
  * log_prob [G][beam][A]; scores [G][beam] in/out; step = current_step (>= 1; at step 1

@@ -557,3 +557,76 @@ def cvrp_train_batch(oracle: "CVRPOracle", xy: Tensor, demand: Tensor, solution:
         with torch.no_grad():
             oracle.step(act[:, t].clone())
     return torch.stack(probs, 0), losses
+
+
+def tsp_train_batch(oracle: "TSPOracle", xy: Tensor, solution: Tensor, lr: float = 1e-4, weight_decay: float = 1e-6):
+    """TSPTrainer._train_one_batch (TSP/TSPTrainer.py:216-256): xy [B,N,2] (the coordinates reset('train')
+    produced), labels solution [B,N]; one torch Adam step per decode step.  Returns probs [N-1][B]."""
+    N = xy.shape[1]
+    opt = torch.optim.Adam(list(oracle.w.values()), lr=lr, weight_decay=weight_decay)
+    oracle.reset(xy)
+    oracle.step(solution[:, 0].clone())
+    probs = []
+    for t in range(1, N):
+        prob, _ = train_forward_backward(oracle, solution[:, t])
+        opt.step()
+        probs.append(prob)
+        with torch.no_grad():
+            oracle.step(solution[:, t].clone())
+    return torch.stack(probs, 0)
+
+
+# --------------------------------------------------------------------------- self-improvement labels
+def tsp_nearest_neighbour(xy: Tensor) -> Tuple[Tensor, Tensor]:
+    """TSPEnv.greedy_search (TSP/TSPEnv.py:140-169): from node 0 to the nearest unvisited node by the cdist
+    matrix; length = sum of the matrix entries around the tour.  Returns (solution [B,N], length [B])."""
+    B, N, _ = xy.shape
+    dis = torch.cdist(xy, xy, p=2)
+    rows = torch.arange(B)
+    sol = torch.zeros(B, 1, dtype=torch.int64)
+    for _ in range(1, N):
+        d = dis[rows, sol[:, -1]].clone()
+        d[rows[:, None], sol] += 1e5
+        sol = torch.cat((sol, torch.argmin(d, dim=1, keepdim=True)), dim=1)
+    length = torch.sum(dis[rows[:, None], sol, torch.roll(sol, -1, dims=1)], dim=1)
+    return sol, length
+
+
+def cvrp_nearest_neighbour(xy: Tensor, demand: Tensor) -> Tuple[Tensor, Tensor]:
+    """CVRPEnv.greedy_search (CVRP/CVRPEnv.py:340-409): xy [B,N+1,2] (depot first), demand [B,N+1]; nearest
+    unvisited customer, via the depot when capacity + 1e-6 < demand (always for the first move).
+    Returns (nodes [B,N], flags [B,N])."""
+    B, M, _ = xy.shape
+    dis = torch.cdist(xy, xy, p=2)
+    rows = torch.arange(B)
+    nodes = torch.zeros(B, 0, dtype=torch.int64)
+    flags = torch.zeros(B, 0, dtype=torch.int64)
+    cap = torch.ones(B)
+    last = torch.zeros(B, dtype=torch.int64)
+    for t in range(M - 1):
+        d = dis[rows, last].clone()
+        d[:, 0] += 1e5
+        d[rows[:, None], nodes] += 1e5
+        nxt = torch.argmin(d, dim=1)
+        dem = demand[rows, nxt]
+        via = torch.ones(B, dtype=torch.bool) if t == 0 else (cap + 0.000001) < dem
+        cap = torch.where(via, 1 - dem, cap - dem)
+        nodes = torch.cat((nodes, nxt[:, None]), dim=1)
+        flags = torch.cat((flags, via.long()[:, None]), dim=1)
+        last = nxt
+    return nodes, flags
+
+
+def cvrp_label_augment(nodes: Tensor, flags: Tensor, flip: Tensor, shift: Tensor) -> Tuple[Tensor, Tensor]:
+    """CVRPEnv.data_augmentation (CVRP/CVRPEnv.py:325-338) with the draws given: flip[i][j] stands for the
+    j-th ``torch.rand(1) > 0.5`` of instance i (j = 1..S-1), shift[i] for its ``randint(0, S)``."""
+    nodes, flags = nodes.clone(), flags.clone()
+    for i in range(nodes.shape[0]):
+        idx = torch.nonzero(flags[i], as_tuple=True)[0]
+        for j in range(1, len(idx)):
+            if flip[i][j]:
+                nodes[i][idx[j - 1]:idx[j]] = torch.flip(nodes[i][idx[j - 1]:idx[j]], [0])
+        k = int(idx[int(shift[i]) % len(idx)])
+        nodes[i] = torch.cat((nodes[i][k:], nodes[i][:k]))
+        flags[i] = torch.cat((flags[i][k:], flags[i][:k]))
+    return nodes, flags

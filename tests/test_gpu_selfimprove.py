@@ -1,0 +1,230 @@
+"""Self-improvement training loop (label construction, replacement, validation rollout with
+keep-if-shorter, label augmentation, training batch) against vectors captured from the reference
+(oracle/make_selfimp_goldens.py) and against the CPU oracle on larger random cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TSP_INFO = [True, True, True, False, True, True, False, False, False, False, False]
+CVRP_INFO = TSP_INFO + [False, False]
+
+
+def _model_params(info):
+    return dict(mode="train", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3, qkv_dim=16,
+                head_num=8, ff_hidden_dim=512, append_information=info)
+
+
+def _trainer(cls, info, g, B, N, extra):
+    from dgl_amd.weights import load_checkpoint
+    tp = dict(use_cuda=True, cuda_device_num=0, knn=int(g["meta/knn"]), beam_size=int(g["meta/beam"]),
+              step_size=int(g["meta/step_size"]), train_batch_size=B, problem_size=N, epochs=10,
+              model_load={"enable": False})
+    tp.update(extra)
+    tr = cls(env_params=dict(mode="train", pomo_size=1, append_information=info, aggregation_nums=10, test_mode="none",
+                             max_replace_ratio=0.4, min_replace_ratio=0.2, data_path=""),
+             model_params=_model_params(info),
+             optimizer_params=dict(optimizer=dict(lr=1e-4, weight_decay=1e-6), scheduler=dict(milestones=[3], gamma=0.1)),
+             trainer_params=tp)
+    name = "ckpt_cvrp_nn.pt" if "depot_knn" in extra else "ckpt_tsp_nn.pt"
+    tr.trainer.load_state_dict(load_checkpoint(os.path.join(GOLDEN, name)))
+    tr._repack()
+    return tr
+
+
+def _check_training(tr, g, what):
+    probs = tr.trainer.last_log_probs.exp().cpu().numpy().T          # [N-1][B]
+    rel = np.abs(probs - g["train/prob"]) / g["train/prob"]
+    print(f"{what}: teacher probabilities over {probs.shape[0]} Adam steps: max relative difference {rel.max():.2e}, "
+          f"median {np.median(rel):.2e}")
+    # a logit error of 1e-3 of its magnitude (tens, for the least likely tokens) is a few per cent of a small probability
+    likely = g["train/prob"] >= 1e-3
+    worst = np.unravel_index(np.argmax(rel), rel.shape)
+    print(f"   largest difference at step {worst[0] + 1}, row {worst[1]}: {probs[worst]:.4e} vs {g['train/prob'][worst]:.4e}")
+    assert np.median(rel) < 1e-4 and rel[likely].max() < 2e-2 and rel.max() < 0.15
+    # Weights: Adam divides every entry's step by the entry's own gradient scale, so an entry whose gradient is
+    # rounding noise (units that are almost dead, the last layer's biases whose gradients vanish identically,
+    # saturated attention) still moves by +-lr per step, in a direction float32 autograd itself does not
+    # reproduce against float64.  Per entry only the hard bound holds; the well-conditioned output layer agrees.
+    sd = tr.trainer.state_dict()
+    steps = probs.shape[0]
+    for k, v in sd.items():
+        if f"final/full/{k}" in g:
+            assert np.abs(v.cpu().numpy() - g[f"final/full/{k}"]).max() <= 2 * steps * 1e-4, k
+    np.testing.assert_allclose(sd["decoder.Linear_final.weight"].cpu().numpy(), g["final/full/decoder.Linear_final.weight"],
+                               rtol=0, atol=2e-5)
+
+
+def test_cvrp_self_improvement_loop_matches_reference(device):
+    from dgl_amd.engine import CvrpEngine
+    from dgl_amd.train import train_one_batch_cvrp
+    from dgl_amd.trainer import CVRPTrainer
+    g = np.load(os.path.join(GOLDEN, "selfimp_cvrp_n30_b6.npz"))
+    p0 = torch.from_numpy(g["problems0"])
+    B, N = p0.shape[0], p0.shape[1] - 1
+    tr = _trainer(CVRPTrainer, CVRP_INFO, g, B, N, dict(depot_knn=int(g["meta/depot_knn"])))
+    env = tr.env
+    env.step_size, env.beam_size = tr.trainer_params["step_size"], tr.trainer_params["beam_size"]
+    torch.manual_seed(4321)
+    env.load_problems(0, B, N)
+    if str(g["meta/torch"]) == torch.__version__:
+        assert torch.equal(env.problems, p0)                        # same host RNG calls as the reference
+    env.depot_node_xy, env.depot_node_demand = p0[:, :, :2].clone(), p0[:, :, 2].clone()
+    env.problems = p0.clone()
+    env.greedy_search()
+    assert np.array_equal(env.solution.cpu().numpy(), g["greedy/solution"])
+    assert np.array_equal(env.solution_flag.cpu().numpy(), g["greedy/flag"])
+    np.testing.assert_allclose(env.solution_len.cpu().numpy(), g["greedy/len"], rtol=2e-6)
+    idx = torch.from_numpy(g["replace/index"])
+    env.replace_size = int(g["meta/replace"])
+    assert tr.replace_size(5) == int((0.2 * 0.5 + 0.2) * B)
+    env.random_replace(idx, torch.from_numpy(g["problems1"])[idx])
+    assert torch.equal(env.problems, torch.from_numpy(g["problems1"]))
+    assert torch.isinf(env.solution_len[idx.to(device)]).all()
+    env.start_idx, chunk = 0, 0
+    while env.start_idx < B:
+        draws = (torch.from_numpy(g[f"chunk{chunk}/flip"]), torch.from_numpy(g[f"chunk{chunk}/shift"]))
+        tr.beamsearch_tour_nodes_shortest(env.beam_size, env.step_size, N + 1, start=torch.from_numpy(g[f"chunk{chunk}/start"]),
+                                          draws=draws)
+        tours, flags, lens = tr.last_shortest
+        assert np.array_equal(tours.cpu().numpy(), g[f"chunk{chunk}/tours"])
+        assert np.array_equal(flags.cpu().numpy(), g[f"chunk{chunk}/flags"])
+        np.testing.assert_allclose(lens.cpu().numpy(), g[f"chunk{chunk}/lens"], rtol=2e-6)
+        np.testing.assert_allclose(env.solution_len.cpu().numpy(), g[f"chunk{chunk}/kept_len"], rtol=2e-6)
+        assert np.array_equal(env.solution.cpu().numpy(), g[f"chunk{chunk}/aug_solution"])
+        assert np.array_equal(env.solution_flag.cpu().numpy(), g[f"chunk{chunk}/aug_flag"])
+        env.start_idx += env.step_size
+        chunk += 1
+    # the training reset under the generator state the reference had
+    torch.manual_seed(int(g["meta/train_seed"]))
+    env.reset("train")
+    assert env.engine.demand_in_distance and env.engine.R == B
+    np.testing.assert_allclose(env.engine.xy.cpu().numpy(), g["train/aug_xy"], rtol=0, atol=2e-6)
+    # the training batch itself on the reference's augmented coordinates
+    env.engine = CvrpEngine(torch.from_numpy(g["train/aug_xy"]).to(device), env.engine.demand, 1, env.knn, env.depot_knn,
+                            demand_in_distance=True)
+    train_one_batch_cvrp(tr.trainer, env.engine, env.solution, env.solution_flag)
+    tr._repack()
+    _check_training(tr, g, "cvrp")
+    # a rollout with the updated weights still runs and improves nothing it should not
+    env.start_idx = 0
+    before = env.solution_len.clone()
+    tr.beamsearch_tour_nodes_shortest(env.beam_size, env.step_size, N + 1)
+    assert (env.solution_len <= before).all()
+
+
+def test_tsp_self_improvement_loop_matches_reference(device):
+    from dgl_amd.engine import TspEngine
+    from dgl_amd.train import train_one_batch_tsp
+    from dgl_amd.trainer import TSPTrainer
+    g = np.load(os.path.join(GOLDEN, "selfimp_tsp_n40_b6.npz"))
+    p0 = torch.from_numpy(g["problems0"])
+    B, N = p0.shape[0], p0.shape[1]
+    tr = _trainer(TSPTrainer, TSP_INFO, g, B, N, {})
+    env = tr.env
+    env.step_size = tr.trainer_params["step_size"]
+    torch.manual_seed(8765)
+    env.load_problems(0, B, N, tr.trainer_params["beam_size"])
+    if str(g["meta/torch"]) == torch.__version__:
+        assert torch.equal(env.problems, p0)
+    env.problems = p0.clone()
+    env.greedy_search()
+    assert np.array_equal(env.solution.cpu().numpy(), g["greedy/solution"])
+    np.testing.assert_allclose(env.solution_len.cpu().numpy(), g["greedy/len"], rtol=2e-6)
+    idx = torch.from_numpy(g["replace/index"])
+    env.replace_size = int(g["meta/replace"])
+    env.random_replace(idx, torch.from_numpy(g["problems1"])[idx])
+    assert torch.equal(env.problems, torch.from_numpy(g["problems1"]))
+    env.start_idx, chunk = 0, 0
+    while env.start_idx < B:
+        tr.beamsearch_tour_nodes_shortest(env.beam_size, env.step_size, N, start=torch.from_numpy(g[f"chunk{chunk}/start"]),
+                                          shift=int(g[f"chunk{chunk}/shift"]))
+        tours, lens = tr.last_shortest
+        assert np.array_equal(tours.cpu().numpy(), g[f"chunk{chunk}/tours"])
+        np.testing.assert_allclose(lens.cpu().numpy(), g[f"chunk{chunk}/lens"], rtol=2e-6)
+        np.testing.assert_allclose(env.solution_len.cpu().numpy(), g[f"chunk{chunk}/kept_len"], rtol=2e-6)
+        assert np.array_equal(env.solution.cpu().numpy(), g[f"chunk{chunk}/aug_solution"])
+        env.start_idx += env.step_size
+        chunk += 1
+    torch.manual_seed(int(g["meta/train_seed"]))
+    env.reset("train")
+    np.testing.assert_allclose(env.engine.xy.cpu().numpy(), g["train/aug_xy"], rtol=0, atol=2e-6)
+    env.engine = TspEngine(torch.from_numpy(g["train/aug_xy"]).to(device), 1, env.knn)
+    train_one_batch_tsp(tr.trainer, env.engine, env.solution)
+    tr._repack()
+    _check_training(tr, g, "tsp")
+
+
+@pytest.mark.parametrize("N", [7, 200, 1000])
+def test_nearest_neighbour_labels_match_oracle(N, device):
+    from oracle import dgl_oracle as O
+    from dgl_amd import CVRPEnv, TSPEnv
+    B = 5
+    torch.manual_seed(100 + N)
+    env = TSPEnv(mode="train", pomo_size=1, append_information=TSP_INFO, device=device, data_path="")
+    env.load_problems(0, B, N, 1)
+    env.greedy_search()
+    sol, length = O.tsp_nearest_neighbour(env.problems)
+    assert torch.equal(env.solution.cpu(), sol)
+    np.testing.assert_allclose(env.solution_len.cpu().numpy(), length.numpy(), rtol=3e-6)
+    cenv = CVRPEnv(mode="train", pomo_size=1, append_information=CVRP_INFO, device=device)
+    cenv.load_problems(0, B, N)
+    cenv.greedy_search()
+    nodes, flags = O.cvrp_nearest_neighbour(cenv.depot_node_xy, cenv.depot_node_demand)
+    assert torch.equal(cenv.solution.cpu(), nodes) and torch.equal(cenv.solution_flag.cpu(), flags)
+    np.testing.assert_allclose(cenv.solution_len.cpu().numpy(), O.cvrp_route_length(cenv.depot_node_xy, nodes, flags).numpy(),
+                               rtol=3e-6)
+    # label augmentation: random draws, both through the oracle's loops and the kernel
+    g = torch.Generator().manual_seed(N)
+    flip = (torch.rand(B, N, generator=g) > 0.5).to(torch.uint8)
+    shift = torch.randint(0, 1 << 20, (B,), generator=g).to(torch.int32)
+    want_n, want_f = O.cvrp_label_augment(nodes, flags, flip, shift)
+    cenv.data_augmentation(flip, shift)
+    assert torch.equal(cenv.solution.cpu(), want_n) and torch.equal(cenv.solution_flag.cpu(), want_f)
+    # the default draws follow the reference's order on the host generator and keep every label a permutation
+    cenv.data_augmentation()
+    assert torch.equal(cenv.solution.cpu().sort(dim=1).values, torch.arange(1, N + 1).expand(B, N))
+    assert (cenv.solution_flag[:, 0] == 1).all()
+
+
+def test_trainer_run_checkpoint_roundtrip(device, tmp_path):
+    """run() over five short epochs: the checkpoint written at epoch 5 has the reference's entries, restores
+    into a new trainer, and its optimizer entry loads into torch.optim.Adam over the same parameters."""
+    from dgl_amd.trainer import CVRPTrainer
+    from dgl_amd.cvrp import CVRPModel
+
+    def make(load):
+        tp = dict(use_cuda=True, cuda_device_num=0, knn=8, depot_knn=6, beam_size=2, step_size=2, train_batch_size=4,
+                  problem_size=12, epochs=5, loops_per_epoch=1, result_folder=str(tmp_path), model_load=load)
+        return CVRPTrainer(env_params=dict(mode="train", pomo_size=1, append_information=CVRP_INFO, aggregation_nums=10,
+                                           test_mode="none", max_replace_ratio=0.5, min_replace_ratio=0.25),
+                           model_params=_model_params(CVRP_INFO),
+                           optimizer_params=dict(optimizer=dict(lr=1e-4, weight_decay=1e-6),
+                                                 scheduler=dict(milestones=[1], gamma=0.1)),
+                           trainer_params=tp)
+    tr = make({"enable": False})
+    w0 = {k: v.clone() for k, v in tr.trainer.state_dict().items()}
+    tr.run()
+    assert tr.trainer.step_count == 5 * 11 and abs(tr.trainer.lr - 1e-5) < 1e-12        # one scheduler step, at the save
+    assert any(not torch.equal(w0[k], v) for k, v in tr.trainer.state_dict().items())
+    path = tmp_path / "checkpoint-5.pt"
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "result_log"}
+    keys, data = ck["result_log"]
+    assert keys == {"train_score", "train_student_score", "train_loss", "replace_score"} and len(data["train_loss"]) == 5
+    model = CVRPModel(**_model_params(CVRP_INFO))
+    model.load_state_dict(ck["model_state_dict"])                               # the reference's keys and shapes
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert len(opt.state) == len(tr.trainer.keys)
+    tr2 = make({"enable": True, "path": str(tmp_path), "epoch": 5})
+    assert tr2.start_epoch == 6 and tr2.trainer.step_count == tr.trainer.step_count
+    for k, v in tr.trainer.state_dict().items():
+        assert torch.equal(v, tr2.trainer.state_dict()[k]), k
+    assert torch.equal(tr.trainer.exp_avg_sq, tr2.trainer.exp_avg_sq)
+    assert tr2.result_log.get("train_loss") == tr.result_log.get("train_loss")

@@ -134,3 +134,37 @@ def test_cvrp_training_batch_oracle_reproduces_reference():
     for k, v in orc.w.items():
         if f"final/norm/{k}" in g:
             np.testing.assert_allclose(float(v.detach().double().norm()), float(g[f"final/norm/{k}"]), rtol=1e-6)
+
+
+def test_self_improvement_label_functions_against_reference():
+    """Nearest-neighbour labels and the CVRP label augmentation of the oracle against the vectors the reference
+    produced (greedy_search, data_augmentation with its recorded draws)."""
+    import numpy as np
+    import torch
+    from oracle import dgl_oracle as O
+    g = np.load(os.path.join(GOLDEN, "selfimp_cvrp_n30_b6.npz"))
+    p = torch.from_numpy(g["problems0"])
+    nodes, flags = O.cvrp_nearest_neighbour(p[:, :, :2].contiguous(), p[:, :, 2].contiguous())
+    assert np.array_equal(nodes.numpy(), g["greedy/solution"]) and np.array_equal(flags.numpy(), g["greedy/flag"])
+    assert np.array_equal(O.cvrp_route_length(p[:, :, :2].contiguous(), nodes, flags).numpy(), g["greedy/len"])
+    for c in (0, 1):
+        a, b = O.cvrp_label_augment(torch.from_numpy(g[f"chunk{c}/kept_solution"]), torch.from_numpy(g[f"chunk{c}/kept_flag"]),
+                                    torch.from_numpy(g[f"chunk{c}/flip"]), torch.from_numpy(g[f"chunk{c}/shift"]))
+        assert np.array_equal(a.numpy(), g[f"chunk{c}/aug_solution"]) and np.array_equal(b.numpy(), g[f"chunk{c}/aug_flag"])
+    t = np.load(os.path.join(GOLDEN, "selfimp_tsp_n40_b6.npz"))
+    sol, length = O.tsp_nearest_neighbour(torch.from_numpy(t["problems0"]))
+    assert np.array_equal(sol.numpy(), t["greedy/solution"]) and np.array_equal(length.numpy(), t["greedy/len"])
+
+
+def test_tsp_training_batch_of_the_oracle_against_reference():
+    """TSPTrainer._train_one_batch restated in the oracle reproduces the reference's teacher probabilities."""
+    import numpy as np
+    import torch
+    from oracle import dgl_oracle as O
+    from dgl_amd.weights import load_checkpoint
+    t = np.load(os.path.join(GOLDEN, "selfimp_tsp_n40_b6.npz"))
+    w = load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt"))
+    orc = O.TSPOracle(w, knn=int(t["meta/knn"]))
+    orc.w = O.enable_grad(w)
+    probs = O.tsp_train_batch(orc, torch.from_numpy(t["train/aug_xy"]), torch.from_numpy(t["chunk1/aug_solution"]))
+    assert np.array_equal(probs.numpy(), t["train/prob"])
