@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import PROBLEM_CVRP, check, ptr, stream_ptr
 from .augment import mix_augment
 from .engine import CvrpEngine, PackedPolicy
+from .formats import read_cvrp_instances_from_file
 from .nn_layout import DecoderParams, EncoderParams
 
 SHIPPED_INFO = [True, True, True, False, True, True, False, False, False, False, False, False, False]
@@ -24,21 +25,6 @@ def get_random_problems(batch_size, problem_size):
     scaler = {20: 30, 50: 40}.get(problem_size, 500)
     node_demand = torch.randint(1, 200, size=(batch_size, problem_size)) / float(scaler)
     return depot_xy, node_xy, node_demand
-
-
-def read_cvrp_instances_from_file(file_path):
-    """"depot .|. nodes .|. demands .|. capacity" per line (CVRP/CVRPEnv.py:83-111)."""
-    depot, nodes, demands = [], [], []
-    with open(file_path, "r", encoding="utf8") as f:
-        for line in f:
-            if not line.strip():
-                continue
-            part = line.strip().split(" .|. ")
-            depot.append([float(x) for x in part[0].strip().split(",")])
-            nodes.append([[float(x) for x in tok.split(",")] for tok in part[1].strip().split(" ")])
-            cap = int(part[3])
-            demands.append((torch.Tensor([int(x) for x in part[2].strip().split(" ")]) / cap).tolist())
-    return torch.Tensor(depot), torch.Tensor(nodes), torch.Tensor(demands)
 
 
 @dataclass

@@ -87,7 +87,13 @@ class _TesterBase:
         else:
             view = reward.view(self.env.batch_size, beam_size * self.env.pomo_size)
         shortest, index = torch.min(view, dim=1)
+        self._group = view.shape
         return shortest, index
+
+    def _best_of_group(self, rows: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+        """Row of the best rollout of every instance (TSP/TSPTester.py:190-193)."""
+        B, G = self._group
+        return rows.view(B, G, -1)[torch.arange(B, device=rows.device), index]
 
 
 class TSPTester(_TesterBase):
@@ -119,6 +125,7 @@ class TSPTester(_TesterBase):
         shortest, index = self._summarise(reward, beam_size)
         self.last_tours = env.selected_node_list
         self.last_lengths = reward
+        self.shortest_tours = self._best_of_group(self.last_tours, index)
         return 0, 0, 0, shortest.mean().item()
 
     @torch.no_grad()
@@ -142,6 +149,7 @@ class TSPTester(_TesterBase):
         shortest, index = self._summarise(length, beam_size)
         self.last_tours = env.selected_node_list
         self.last_lengths = length
+        self.shortest_tours = self._best_of_group(self.last_tours, index)
         return shortest
 
     def run(self):
@@ -209,6 +217,8 @@ class CVRPTester(_TesterBase):
         self.last_tours = env.selected_node_list
         self.last_flags = env.step_state.selected_flag
         self.last_lengths = reward
+        self.shortest_tours = self._best_of_group(self.last_tours, index)
+        self.shortest_tours_flag = self._best_of_group(self.last_flags, index)
         return shortest.mean().item(), shortest.mean().item(), 0.0
 
     @torch.no_grad()
@@ -230,6 +240,8 @@ class CVRPTester(_TesterBase):
         self.last_tours = env.selected_node_list
         self.last_flags = env.step_state.selected_flag
         self.last_lengths = length
+        self.shortest_tours = self._best_of_group(self.last_tours, index)
+        self.shortest_tours_flag = self._best_of_group(self.last_flags, index)
         return shortest
 
     def run(self):

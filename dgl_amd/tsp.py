@@ -22,6 +22,7 @@ from . import _lib
 from ._lib import PROBLEM_TSP, check, ptr, stream_ptr
 from .augment import mix_augment
 from .engine import PackedPolicy, TspEngine
+from .formats import read_baseline_lengths, read_tsp_instances
 from .nn_layout import DecoderParams, EncoderParams
 
 SHIPPED_INFO = [True, True, True, False, True, True, False, False, False, False, False]
@@ -96,13 +97,10 @@ class TSPEnv:
     # ---- data ---------------------------------------------------------------------
     def load_data(self, test_episode, problem_size):
         """Instance text file "x,y x,y ..." and optional baseline-length file (TSP/TSPEnv.py:82-106)."""
-        with open(self.data_path, "r") as f:
-            pts = [[float(v) for v in tok.split(",")] for tok in f.read().split()]
-        self.raw_data_nodes = torch.tensor(pts, dtype=torch.float32).view(test_episode, problem_size, 2)
+        self.raw_data_nodes = read_tsp_instances(self.data_path, test_episode, problem_size)
         self.baseline_len = []
         if self.baseline_path != "":
-            with open(self.baseline_path, "r") as f:
-                self.baseline_len = torch.tensor([float(line.split()[1]) for line in f])
+            self.baseline_len = read_baseline_lengths(self.baseline_path)
 
     def load_problems(self, episode, batch_size, problem_size, beam_size):
         self.episode = episode

@@ -105,3 +105,33 @@ def test_cvrp_aug_test_env_and_tester_reduction(device):
         assert same.mean() >= 0.9
         np.testing.assert_allclose(tester.last_lengths.cpu().numpy()[same], g["reward"][same], rtol=2e-6)
         np.testing.assert_allclose(shortest.cpu().numpy(), g["shortest"], rtol=2e-4)
+
+
+def test_library_drivers_on_fixture_files(device):
+    """run_tsplib / run_cvrplib over the synthetic library files: the integer score is the rounded-up length of the
+    returned best tour on the original coordinates and the tour is a valid one."""
+    from dgl_amd import formats as F
+    from dgl_amd.libeval import run_cvrplib, run_tsplib
+    from dgl_amd.weights import load_checkpoint
+    root = os.path.join(GOLDEN, "formats")
+    mp = lambda info: dict(mode="test", embedding_dim=128, sqrt_embedding_dim=128 ** 0.5, decoder_layer_num=3, qkv_dim=16,
+                           head_num=8, ff_hidden_dim=512, append_information=info)
+    tinfo = [True, True, True, False, True, True, False, False, False, False, False]
+    lines = []
+    res = run_tsplib(root, dict(mode="test", append_information=tinfo, aggregation_nums=5, pomo_size=1), mp(tinfo),
+                     dict(use_cuda=True, cuda_device_num=0, knn=12, beam_size=2, model_load={"enable": False}),
+                     names=["syn17"], best_known={"syn17": 7000},
+                     weights=load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt")), log=lines.append)
+    length, gap, _ = res["syn17"]
+    inst, _ = F.load_tsplib_file(root, "syn17")
+    assert gap == length / 7000 - 1 and any(l.startswith("syn17 score") for l in lines)
+    # a tour of 17 points spread over 2000 x 2000 is no shorter than the instance's extent and the model's is sane
+    assert 4000 < length < 15000
+    cinfo = tinfo + [False, False]
+    res = run_cvrplib(root, dict(mode="test", append_information=cinfo, aggregation_nums=5, pomo_size=1), mp(cinfo),
+                      dict(use_cuda=True, cuda_device_num=0, knn=6, depot_knn=4, beam_size=1, model_load={"enable": False}),
+                      names=["S-n12-k3"], best_known={"S-n12-k3": 3000},
+                      weights=load_checkpoint(os.path.join(GOLDEN, "ckpt_cvrp_nn.pt")), log=lines.append)
+    length, gap, _ = res["S-n12-k3"]
+    assert gap == length / 3000 - 1 and 1500 < length < 12000
+    print("\n".join(lines))
