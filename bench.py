@@ -52,6 +52,19 @@ def knn_bytes_per_row(nodes: int, k: int, cvrp: bool) -> float:
     return 24 * nodes + nodes / 8 + 8 * k
 
 
+def pmc_traffic(args, B, knn, kernel):
+    """HBM-side bytes per launch of ``kernel`` from the committed counter pass of this workload (the counters
+    cannot be read from inside the process); None when no pass was recorded for it."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    entry = rec.get(f"{args.problem}{args.nodes}_b{B}_k{knn}", {}).get(kernel)
+    return entry["bytes_per_launch"] if entry else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,13 +199,16 @@ def main():
             "mean_tour_length": mean_len,
             "roofline": {"kernel": "policy_kernel_f16" if split else "policy_kernel_f32", "bound": "mfma",
                          "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
-                         "traffic": None, "avg_launch_ms": ms_policy, "flops_per_launch": flops,
+                         "traffic": pmc_traffic(args, B, knn, "policy_kernel_f16" if split else "policy_kernel_f32"),
+                         "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC pass recorded in profiles/pmc_traffic.json",
+                         "avg_launch_ms": ms_policy, "flops_per_launch": flops,
                          "samples": len(ev_policy), "event_interval_ms": raw_policy, "empty_event_interval_ms": ms_null,
                          "peak_note": (f"dense f16 MFMA peak {PEAK_F16_MATRIX_TFLOPS} / {SPLIT_PASSES} passes per "
                                        "f32-accurate product" if split else "dense f32-input MFMA peak"),
                          "frac_of_f16_dense_peak": ach_tf / PEAK_F16_MATRIX_TFLOPS},
             "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS, "traffic": None,
+                             "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
+                             "traffic": pmc_traffic(args, B, knn, "step_kernel"),
                              "avg_launch_ms": ms_knn, "event_interval_ms": raw_knn, "bytes_per_launch": bytes_knn, "rows": B},
         }
         if not args.no_aux and world == 1:

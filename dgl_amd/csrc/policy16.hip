@@ -41,18 +41,27 @@ __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x
 
 #define NVEC (PK_STREAM0 - PK_VEC0)              // bias vectors + final weights, staged in LDS
 
-// Split of activations: hi = v with its significand truncated to 11 bits (exactly representable
-// in binary16 for |v| in [2^-14, 65520)), lo = v - hi (exact), both converted with the packed
-// round-towards-zero instruction: three VALU operations per value, 22 significant bits kept.
-// Larger magnitudes saturate at the largest finite binary16, smaller ones keep an absolute
-// accuracy of 2^-24.
+// Split of activations: hi = binary16(v) rounded towards zero (one packed conversion for two values),
+// lo = binary16(v - hi), the difference formed exactly by one mixed-precision FMA that reads hi
+// straight from the packed register: four VALU operations per pair, 22 significant bits kept.
+// Magnitudes above 65504 saturate in hi and continue in lo; below 2^-14 the absolute accuracy is 2^-24.
 __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
+// a - (low / high half of hh, read as binary16), exact in binary32
+__device__ __forceinline__ float minus_half_lo(float a, unsigned hh) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float minus_half_hi(float a, unsigned hh) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
-    const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u), bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-    hi = pack_rtz(ah, bh);
-    lo = pack_rtz(a - ah, b - bh);
+    hi = pack_rtz(a, b);
+    lo = pack_rtz(minus_half_lo(a, hi), minus_half_hi(b, hi));
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -348,25 +357,28 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                 // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
                 // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
                 //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
-                float mx = -INFINITY;
+                if (n < 32) {                                    // wave-uniform: a full tile has no padded key
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    const int j = (m & 3) + 8 * (m >> 2) + 4 * h;
-                    s[m] = (j < n) ? s[m] : -INFINITY;
-                    mx = fmaxf(mx, s[m]);
+                    for (int m = 0; m < 16; ++m) {
+                        const int j = (m & 3) + 8 * (m >> 2) + 4 * h;
+                        s[m] = (j < n) ? s[m] : -INFINITY;
+                    }
                 }
+                float mx = s[0];
+#pragma unroll
+                for (int m = 1; m < 16; ++m) mx = fmaxf(mx, s[m]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float off = -mx * 0.36067376022224085f;
                 float sum = 0.0f;
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
-                    s[m] = __builtin_amdgcn_exp2f((s[m] - mx) * 0.36067376022224085f);
+                    s[m] = __builtin_amdgcn_exp2f(fmaf(s[m], 0.36067376022224085f, off));
                     sum += s[m];
                 }
                 sum += __shfl_xor(sum, 32, 64);
                 const float inv = 1.0f / sum;
-#pragma unroll
-                for (int m = 0; m < 16; ++m) s[m] = s[m] * inv;
-                // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7
+                // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7.  The weights
+                // enter unnormalised (largest = 1); the eight outputs are divided by their sum afterwards.
                 f32x16 o = zero16();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                     o = MFMA16(vh[t], ph, o);
                 }
 #pragma unroll
-                for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m];
+                for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m] * inv;
             }
             store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr);
         }
@@ -456,11 +468,11 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
                             v0[rr] = fmaxf(ah[rr][2 * st] + bb[g][e], 0.0f);
                             v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
                         } else if constexpr (part == 1) {
-                            t0[rr] = __uint_as_float(__float_as_uint(v0[rr]) & 0xFFFFE000u);
-                            t1[rr] = __uint_as_float(__float_as_uint(v1[rr]) & 0xFFFFE000u);
-                            hq[rr] = pack_rtz(t0[rr], t1[rr]);
+                            hq[rr] = pack_rtz(v0[rr], v1[rr]);
+                            t0[rr] = minus_half_lo(v0[rr], hq[rr]);
+                            t1[rr] = minus_half_hi(v1[rr], hq[rr]);
                         } else {
-                            lq[rr] = pack_rtz(v0[rr] - t0[rr], v1[rr] - t1[rr]);
+                            lq[rr] = pack_rtz(t0[rr], t1[rr]);
                             if constexpr (st & 1) {
                                 *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
                                 *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};

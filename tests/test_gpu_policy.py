@@ -43,7 +43,7 @@ def test_tsp_split_f16_agrees_with_f32(R, weights, device):
     rel = float((np.abs(a[0] - b[0]) / scale).max())
     print(f"R={R} {weights}: max relative logit difference split-f16 vs f32 kernels {rel:.2e}")
     assert rel < 2e-5                               # both are f32-accurate evaluations of the same sums
-    np.testing.assert_allclose(a[1], b[1], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(a[1], b[1], rtol=5e-4, atol=1e-7)   # relative probability error = absolute logit error
     assert (a[2] == b[2]).mean() >= 0.99
 
 
