@@ -66,7 +66,9 @@ __device__ __forceinline__ float cvrp_features(const dgl_cvrp_state_t &st, const
 #define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
 
 // One wave per row.  LDS per wave: keysL[M] + keysD[M] + tile[(knn+depot_knn+2)*STRIDE] + scratch[128].
-template <int WAVES, bool UPDATE, bool D3>
+// SPLIT: the WAVES waves of a workgroup share one row (each scans a contiguous part of the nodes, wave 0
+// selects and writes the tiles), as in tsp_step_kernel.
+template <int WAVES, bool UPDATE, bool D3, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
@@ -75,13 +77,19 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
                                                               float *__restrict__ tile_out, int lds_per_wave) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * WAVES + wave;
+    const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
     if (r >= st.R) return;
     const int N = st.N, M = N + 1, W = (M + 63) / 64;
-    float *keysL = lds + (size_t)wave * lds_per_wave;
+    float *keysL = lds + (SPLIT ? 0 : (size_t)wave * lds_per_wave);
     float *keysD = keysL + M;
     float *tile = keysD + M;
     float *scratch = tile + (knn + depot_knn + 2) * DGL_TILE_STRIDE;
+    int j_begin = 0, j_end = M;                                // this wave's node range: whole groups of chunks
+    if (SPLIT) {
+        const int per = ((W + WAVES - 1) / WAVES + STEP_UNROLL - 1) / STEP_UNROLL * STEP_UNROLL;
+        j_begin = wave * per * 64;
+        j_end = min(M, j_begin + per * 64);
+    }
 
     const int b = r / st.rows_per_instance;
     CvrpRowCtx cx;
@@ -125,18 +133,18 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         }
     };
     Group nxt;
-    request(0, nxt);
+    request(j_begin, nxt);
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
     // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
     unsigned long long vis_words = 0;
-    for (int j0 = 0; j0 < M; j0 += 64 * STEP_UNROLL) {
+    for (int j0 = j_begin; j0 < j_end; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
-        if (j0 + 64 * STEP_UNROLL < M) request(j0 + 64 * STEP_UNROLL, nxt);
-        if (want_knn && ((j0 >> 6) & 63) == 0) vis_words = vis[min((j0 >> 6) + lane, W - 1)];
+        if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
+        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis[min(((j0 >> 6) & ~63) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
-            if (j < M) {
+            if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3>(x, y, g.dm[q]);
                 const float cross = cvrp_cross<D3>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
@@ -171,7 +179,14 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         // (CVRP/CVRPModel.py:164-166); the nudged value is what the next step starts from.
         if (cap < 0.00001f) cap = __fadd_rn(cap, 0.0000001f);
     }
-    if (lane == 0) {
+    if (SPLIT) {
+        float *mins = scratch + 128;
+        mins[threadIdx.x] = minL;
+        mins[WAVES * 64 + threadIdx.x] = minD;
+        // every wave has read the row's capacity; keys, minima and the avg/sd stores of every wave are complete
+        __syncthreads();
+    }
+    if (lane == 0 && (!SPLIT || wave == 0)) {
         st.capacity[r] = cap;
         if (UPDATE) {
             st.nodes[(size_t)r * N + (t - 1)] = cur;
@@ -182,8 +197,21 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     if (!want_knn) return;
 
     // LDS keys of all lanes, and (for the feature loads below) the avg/sd stores of all lanes
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    // SPLIT: wave 0 builds the group of the current node, wave 1 the depot's group, side by side
+    const bool do_last = !SPLIT || wave == 0, do_depot = !SPLIT || wave == 1;
+    if (SPLIT) {
+        if (wave >= 2) return;
+        const float *mins = scratch + 128;
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            minL = fminf(minL, mins[64 * w + lane]);
+            minD = fminf(minD, mins[WAVES * 64 + 64 * w + lane]);
+        }
+        if (wave == 1) scratch += 128 + 2 * WAVES * 64;        // a search scratch of its own
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     const int kd = min(depot_knn, N - t);                      // CVRP/CVRPModel.py:58,88
     const int kl = min(knn, kd);                               // :123
     const bool low = cap < 0.00001f;
@@ -200,7 +228,9 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     };
     float ckey;
     int cj;
-    int c = wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
+    int c = -1;
+    if (do_last) {
+    c = wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
     if (c >= 0) {
         // inputs of every candidate's row (and of the anchor, on lane 63 when it holds no candidate)
         // are requested before the ranking bisection
@@ -228,7 +258,10 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         });
         if (lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     }
+    for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
     wave_lds_sync();                                           // scratch is reused by the second search
+    }
+    if (do_depot) {
     // neighbourhood of the depot: column 3 holds distance_to_depot (CVRP/CVRPModel.py:180-183)
     c = wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj);
     if (c >= 0) {
@@ -255,16 +288,16 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         });
         if (lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     }
-    for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
     for (int e = kd + lane; e < depot_knn; e += 64) id[e] = -1;
     wave_lds_sync();
+    }
 
     float *tout = tile_out + (size_t)r * (knn + depot_knn + 2) * DGL_TILE_STRIDE;
     float *toutD = tout + (kl + 1) * DGL_TILE_STRIDE;
     // min-max per group (CVRP/CVRPModel.py:299,301); the column after the data is the group flag (:303-304)
-    wave_minmax_norm_store(tileL, kl + 1, CVRP_F, 0.0f, tout, scratch);
+    if (do_last) wave_minmax_norm_store(tileL, kl + 1, CVRP_F, 0.0f, tout, scratch);
     wave_lds_sync();                                           // scratch is reused
-    wave_minmax_norm_store(tileD, kd + 1, CVRP_F, 1.0f, toutD, scratch);
+    if (do_depot) wave_minmax_norm_store(tileD, kd + 1, CVRP_F, 1.0f, toutD, scratch);
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
@@ -362,8 +395,16 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    // few rows: one wave per workgroup spreads them over all CUs
-    if (lds4 <= 64 * 1024 && st->R >= 2048) {
+    const size_t lds_split = (size_t)(per_wave + 512 + 128) * sizeof(float);
+    if (st->R < 2048 && st->N >= 512 && lds_split <= 150 * 1024) {
+        // few rows: four waves share a row
+        if (lds_split > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<4, UPDATE, D3, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                           *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                           per_wave);
+    } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
                            per_wave);

@@ -47,18 +47,29 @@ __device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const Ts
 
 #define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
 
-template <int WAVES, bool UPDATE>
+// SPLIT: the WAVES waves of a workgroup share ONE row: each scans a contiguous quarter of the nodes
+// (state update + keys into the shared LDS array), then wave 0 alone selects and writes the tile.
+// With few rows this is what hides the memory latency of the scan (one wave per row leaves most
+// SIMDs with a single wave and every load exposed).  LDS: the row's arrays + 64 * WAVES lane minima.
+template <int WAVES, bool UPDATE, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
                                                              float *__restrict__ tile_out, int lds_per_wave) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * WAVES + wave;
-    if (r >= st.R) return;                                  // wave-uniform; no block barrier is used below
+    const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
+    if (r >= st.R) return;                                  // uniform over the waves that meet at a barrier below
     const int N = st.N, W = (N + 63) / 64;
-    float *keys = lds + (size_t)wave * lds_per_wave;
+    float *keys = lds + (SPLIT ? 0 : (size_t)wave * lds_per_wave);
     float *tile = keys + N;
     float *scratch = tile + (knn + 1) * DGL_TILE_STRIDE;
+    // this wave's node range [j_begin, j_end): whole groups of STEP_UNROLL chunks
+    int j_begin = 0, j_end = N;
+    if (SPLIT) {
+        const int per = ((W + WAVES - 1) / WAVES + STEP_UNROLL - 1) / STEP_UNROLL * STEP_UNROLL;
+        j_begin = wave * per * 64;
+        j_end = min(N, j_begin + per * 64);
+    }
 
     const int b = r / st.rows_per_instance;
     TspRowCtx cx;
@@ -94,18 +105,18 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         }
     };
     Group nxt;
-    request(0, nxt);
+    request(j_begin, nxt);
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
     // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
     unsigned long long vis_words = 0;
-    for (int j0 = 0; j0 < N; j0 += 64 * STEP_UNROLL) {
+    for (int j0 = j_begin; j0 < j_end; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
-        if (j0 + 64 * STEP_UNROLL < N) request(j0 + 64 * STEP_UNROLL, nxt);
-        if (want_knn && ((j0 >> 6) & 63) == 0) vis_words = vis[min((j0 >> 6) + lane, W - 1)];
+        if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
+        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis[min(((j0 >> 6) & ~63) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
-            if (j < N) {
+            if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
                 const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
@@ -132,15 +143,26 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
             }
         }
     }
-    if (UPDATE && lane == 0) {
+    // (a wave that still scans may read the visited word with this bit already set: it excludes `cur` anyway)
+    if (UPDATE && lane == 0 && (!SPLIT || wave == 0)) {
         st.tour[cx.rowN + (t - 1)] = cur;
         vis[cur >> 6] |= 1ull << (cur & 63);
     }
     if (!want_knn) return;
 
     // LDS keys of all lanes, and (for the staging loads below) the avg/sd stores of all lanes
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    if (SPLIT) {
+        float *mins = scratch + 128;
+        mins[threadIdx.x] = lane_min;
+        __syncthreads();                                    // keys, minima and the avg/sd stores of every wave
+        if (wave != 0) return;
+        // the 64 classes {lane of any wave} partition the keys as the lanes of one wave do
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) lane_min = fminf(lane_min, mins[64 * w + lane]);
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     const int k = min(knn, u);
     int32_t *idx_row = idx_out + (size_t)r * knn;
     float ckey;
@@ -251,8 +273,15 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
                            float *tile_out, dgl_stream_t stream, const char *what) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    // few rows: one wave per workgroup spreads them over all CUs
-    if (lds4 <= 64 * 1024 && st->R >= 2048) {
+    const size_t lds_split = (size_t)(per_wave + 256) * sizeof(float);
+    if (st->R < 2048 && st->N >= 512 && lds_split <= 150 * 1024) {
+        // few rows: four waves share a row
+        if (lds_split > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+        hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                           *st, selected, t, knn, idx_out, tile_out, per_wave);
+    } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, selected, t, knn, idx_out, tile_out, per_wave);
     } else {
