@@ -396,7 +396,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     const size_t lds_split = (size_t)(per_wave + 512 + 128) * sizeof(float);
-    if (st->R < 2048 && st->N >= 512 && lds_split <= 150 * 1024) {
+    if ((st->R < 2048 || st->R >= 8192) && st->N >= 512 && lds_split <= 150 * 1024) {
         // few rows: four waves share a row
         if (lds_split > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<4, UPDATE, D3, true>,

@@ -6,6 +6,8 @@
 // are [R][N] binary32, the visited set is a bitmask.  No [N][N] distance matrix and no
 // [R][N][7] feature tensor exist: distances are recomputed with the reference's exact
 // arithmetic wherever they are needed.
+#include <cstdlib>
+
 #include "common.h"
 #include "select.h"
 #include "state_common.h"
@@ -274,7 +276,10 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     const size_t lds_split = (size_t)(per_wave + 256) * sizeof(float);
-    if (st->R < 2048 && st->N >= 512 && lds_split <= 150 * 1024) {
+    static const int force_split = getenv("DGL_STEP_SPLIT") ? atoi(getenv("DGL_STEP_SPLIT")) : -1;   // experiments
+    // measured at N = 1000: sharing a row wins below 2048 rows (latency) and from 8192 rows on (6-10 %)
+    const bool split = force_split >= 0 ? force_split != 0 : ((st->R < 2048 || st->R >= 8192) && st->N >= 512);
+    if (split && lds_split <= 150 * 1024) {
         // few rows: four waves share a row
         if (lds_split > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
