@@ -87,15 +87,24 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; DGL_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on one card
+    backend = os.environ.get("DGL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from dgl_amd import build
-    build.build()                                   # no-op when the in-tree library is current
+    if local_rank == 0:
+        build.build()                               # no-op when the in-tree library is current
+    if dist is not None:
+        dist.barrier()                              # the other ranks load the library only after that
     from dgl_amd._lib import ARITH_F32, ARITH_SPLIT_F16, PROBLEM_CVRP, PROBLEM_TSP
     from dgl_amd.engine import CvrpEngine, PackedPolicy, TspEngine
     from dgl_amd.weights import random_state_dict
