@@ -54,6 +54,26 @@ def test_uniform(device, N, knn):
     _run_case(device, xy, order, knn)
 
 
+@pytest.mark.parametrize("N,knn,until", [(513, 30, None), (600, 64, 80), (777, 100, 60), (1100, 30, 50)])
+def test_uniform_rows_shared_by_four_waves(device, N, knn, until):
+    """From 512 nodes on (and with few rows) four waves share a row: ragged quarters, k > 64, and for N = 513 the
+    whole tour down to the last node."""
+    rng = np.random.default_rng(N * 1000 + knn)
+    xy = rng.random((2, N, 2), dtype=np.float32)
+    order = np.stack([rng.permutation(N) for _ in range(2)])
+    _run_case(device, xy, order, knn, check_until=until)
+
+
+def test_many_rows_shared_by_four_waves(device):
+    """The saturating-batch variant of the same kernel (8192 rows and more)."""
+    rng = np.random.default_rng(99)
+    B, N = 8192, 512
+    xy = rng.random((B, N, 2), dtype=np.float32)
+    order = np.stack([rng.permutation(N)[:4] for _ in range(B)])
+    order = np.concatenate((order, np.zeros((B, N - 4), dtype=order.dtype)), axis=1)
+    _run_case(device, xy, order, 30, check_until=2)
+
+
 def test_duplicate_points_tie_break(device):
     """Many coincident points: equal keys; the lowest index must win."""
     rng = np.random.default_rng(7)
