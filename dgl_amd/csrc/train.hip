@@ -144,125 +144,137 @@ __global__ void gather_tile_kernel(const float *__restrict__ tile, int row_strid
 }
 
 // ---------------------------------------------------------------------------- attention
-// One workgroup per (row, head); thread i = query token (n <= 256).  Q, K, V: [M][128] (head h =
-// columns 16h..16h+15).  P[r][h][i][j] = softmax_j(q_i.k_j / 4) is stored for the backward pass.
-// (TSP/TSPModel.py:420-441)
+// One workgroup per (row, head), n <= 256 tokens, head h = columns 16h..16h+15 of Q, K, V [M][128]
+// (TSP/TSPModel.py:420-441): P[i][j] = softmax_j(q_i.k_j / 4), O_i = sum_j P[i][j] V_j.
+// The n x n probabilities are never stored: every pass recomputes q.k from the head's K (V, Q, dO)
+// rows held in LDS and read as broadcasts; the backward pass gets the row maximum and the row sum
+// of exponentials from the forward pass (stats [R][8][n][2]) and uses
+//     sum_j P[i][j] dP[i][j] = dO_i . O_i.
+__device__ __forceinline__ float dot16(const float (&a)[HDIM], const float *__restrict__ b) {
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float s = 0.0f;
+#pragma unroll
+    for (int v = 0; v < HDIM / 4; ++v) {
+        const float4 t = b4[v];
+        s = fmaf(a[4 * v], t.x, s);
+        s = fmaf(a[4 * v + 1], t.y, s);
+        s = fmaf(a[4 * v + 2], t.z, s);
+        s = fmaf(a[4 * v + 3], t.w, s);
+    }
+    return s;
+}
+__device__ __forceinline__ void axpy16(float (&acc)[HDIM], float a, const float *__restrict__ b) {
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+#pragma unroll
+    for (int v = 0; v < HDIM / 4; ++v) {
+        const float4 t = b4[v];
+        acc[4 * v] = fmaf(a, t.x, acc[4 * v]);
+        acc[4 * v + 1] = fmaf(a, t.y, acc[4 * v + 1]);
+        acc[4 * v + 2] = fmaf(a, t.z, acc[4 * v + 2]);
+        acc[4 * v + 3] = fmaf(a, t.w, acc[4 * v + 3]);
+    }
+}
+// copies the head's 16 columns of `src` rows tok0..tok0+n-1 into dst[n][16]
+__device__ __forceinline__ void stage_head(const float *__restrict__ src, long tok0, int n, int hd, float *dst) {
+    for (int e = threadIdx.x; e < n * (HDIM / 4); e += blockDim.x) {
+        const int t = e / (HDIM / 4), v = e % (HDIM / 4);
+        reinterpret_cast<float4 *>(dst)[e] =
+            *reinterpret_cast<const float4 *>(src + (tok0 + t) * D_MODEL + hd * HDIM + 4 * v);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
-                                                       const float *__restrict__ V, int n, float *__restrict__ P,
+                                                       const float *__restrict__ V, int n, float *__restrict__ stats,
                                                        float *__restrict__ O) {
     extern __shared__ float sm[];              // K[n][16], V[n][16]
     float *Ks = sm, *Vs = sm + n * HDIM;
     const int r = blockIdx.x, hd = blockIdx.y, i = threadIdx.x;
     const long tok0 = (long)r * n;
-    for (int e = threadIdx.x; e < n * HDIM; e += blockDim.x) {
-        const int t = e / HDIM, d = e % HDIM;
-        Ks[e] = K[(tok0 + t) * D_MODEL + hd * HDIM + d];
-        Vs[e] = V[(tok0 + t) * D_MODEL + hd * HDIM + d];
-    }
+    stage_head(K, tok0, n, hd, Ks);
+    stage_head(V, tok0, n, hd, Vs);
     __syncthreads();
     if (i >= n) return;
     float q[HDIM];
 #pragma unroll
     for (int d = 0; d < HDIM; ++d) q[d] = Q[(tok0 + i) * D_MODEL + hd * HDIM + d];
-    float *prow = P + (((long)r * HEADS + hd) * n + i) * n;
     float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int d = 0; d < HDIM; ++d) s = fmaf(q[d], Ks[j * HDIM + d], s);
-        s = s / 4.0f;
-        prow[j] = s;
-        mx = fmaxf(mx, s);
-    }
+    for (int j = 0; j < n; ++j) mx = fmaxf(mx, dot16(q, Ks + j * HDIM) / 4.0f);
     float sum = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float e = expf(prow[j] - mx);
-        prow[j] = e;
-        sum += e;
-    }
+    for (int j = 0; j < n; ++j) sum += expf(dot16(q, Ks + j * HDIM) / 4.0f - mx);
     float o[HDIM];
 #pragma unroll
     for (int d = 0; d < HDIM; ++d) o[d] = 0.0f;
     for (int j = 0; j < n; ++j) {
-        const float p = prow[j] / sum;
-        prow[j] = p;
-#pragma unroll
-        for (int d = 0; d < HDIM; ++d) o[d] = fmaf(p, Vs[j * HDIM + d], o[d]);
+        const float p = expf(dot16(q, Ks + j * HDIM) / 4.0f - mx) / sum;
+        axpy16(o, p, Vs + j * HDIM);
     }
 #pragma unroll
     for (int d = 0; d < HDIM; ++d) O[(tok0 + i) * D_MODEL + hd * HDIM + d] = o[d];
+    float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
+    st[0] = mx;
+    st[1] = sum;
 }
 
-// Backward of the above.  dO [M][128] -> dQ, dK, dV [M][128]; P is overwritten by dS.
+// Backward of the above.  dO, O [M][128] -> dQ, dK, dV [M][128].
+//   dS[i][j] = P[i][j] (dO_i . V_j - dO_i . O_i) / 4 (gradient with respect to q.k, the 1/4 included)
+//   dQ_i = sum_j dS[i][j] K_j;  dK_j = sum_i dS[i][j] Q_i;  dV_j = sum_i P[i][j] dO_i
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
-                                                       const float *__restrict__ V, const float *__restrict__ dO, int n,
-                                                       float *__restrict__ P, float *__restrict__ dQ,
+                                                       const float *__restrict__ V, const float *__restrict__ O,
+                                                       const float *__restrict__ dO, int n,
+                                                       const float *__restrict__ stats, float *__restrict__ dQ,
                                                        float *__restrict__ dK, float *__restrict__ dV) {
-    extern __shared__ float sm[];              // Q, K, V, dO: [n][16] each
+    extern __shared__ float sm[];              // Q, K, V, dO: [n][16] each; row max, 1 / row sum, dO.O: [n] each
     float *Qs = sm, *Ks = Qs + n * HDIM, *Vs = Ks + n * HDIM, *Gs = Vs + n * HDIM;
+    float *Mx = Gs + n * HDIM, *Inv = Mx + n, *Dt = Inv + n;
     const int r = blockIdx.x, hd = blockIdx.y, i = threadIdx.x;
     const long tok0 = (long)r * n;
-    for (int e = threadIdx.x; e < n * HDIM; e += blockDim.x) {
-        const int t = e / HDIM, d = e % HDIM;
-        const long g = (tok0 + t) * D_MODEL + hd * HDIM + d;
-        Qs[e] = Q[g]; Ks[e] = K[g]; Vs[e] = V[g]; Gs[e] = dO[g];
-    }
-    __syncthreads();
-    float *Pb = P + ((long)r * HEADS + hd) * n * n;
+    stage_head(Q, tok0, n, hd, Qs);
+    stage_head(K, tok0, n, hd, Ks);
+    stage_head(V, tok0, n, hd, Vs);
+    stage_head(dO, tok0, n, hd, Gs);
     const bool live = i < n;
-    // dV_j = sum_i P[i][j] dO_i            (thread = key j)
     if (live) {
-        float a[HDIM];
+        const float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
+        Mx[i] = st[0];
+        Inv[i] = 1.0f / st[1];
+        float d = 0.0f;
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) a[d] = 0.0f;
-        for (int t = 0; t < n; ++t) {
-            const float p = Pb[(long)t * n + i];
-#pragma unroll
-            for (int d = 0; d < HDIM; ++d) a[d] = fmaf(p, Gs[t * HDIM + d], a[d]);
+        for (int c = 0; c < HDIM; ++c) {
+            const long g = (tok0 + i) * D_MODEL + hd * HDIM + c;
+            d = fmaf(dO[g], O[g], d);
         }
-#pragma unroll
-        for (int d = 0; d < HDIM; ++d) dV[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
+        Dt[i] = d;
     }
     __syncthreads();
-    // dS[i][j] = P[i][j] (dP[i][j] - sum_j' P[i][j'] dP[i][j']),  dP[i][j] = dO_i . V_j;  dQ_i = sum_j dS[i][j] K_j / 4
-    if (live) {
-        float *prow = Pb + (long)i * n;
-        float go[HDIM], a[HDIM];
+    if (!live) return;
+    {   // thread = query i
+        float q[HDIM], go[HDIM], a[HDIM];
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) { go[d] = Gs[i * HDIM + d]; a[d] = 0.0f; }
-        float dot = 0.0f;
+        for (int d = 0; d < HDIM; ++d) { q[d] = Qs[i * HDIM + d]; go[d] = Gs[i * HDIM + d]; a[d] = 0.0f; }
+        const float mx = Mx[i], inv = Inv[i], dt = Dt[i];
         for (int j = 0; j < n; ++j) {
-            float dp = 0.0f;
-#pragma unroll
-            for (int d = 0; d < HDIM; ++d) dp = fmaf(go[d], Vs[j * HDIM + d], dp);
-            dot = fmaf(prow[j], dp, dot);
-        }
-        for (int j = 0; j < n; ++j) {
-            float dp = 0.0f;
-#pragma unroll
-            for (int d = 0; d < HDIM; ++d) dp = fmaf(go[d], Vs[j * HDIM + d], dp);
-            const float ds = prow[j] * (dp - dot) / 4.0f;       // gradient with respect to q.k (the 1/4 included)
-            prow[j] = ds;
-#pragma unroll
-            for (int d = 0; d < HDIM; ++d) a[d] = fmaf(ds, Ks[j * HDIM + d], a[d]);
+            const float p = expf(dot16(q, Ks + j * HDIM) / 4.0f - mx) * inv;
+            const float ds = p * (dot16(go, Vs + j * HDIM) - dt) / 4.0f;
+            axpy16(a, ds, Ks + j * HDIM);
         }
 #pragma unroll
         for (int d = 0; d < HDIM; ++d) dQ[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
     }
-    __threadfence_block();
-    __syncthreads();
-    // dK_j = sum_i dS[i][j] Q_i            (thread = key j)
-    if (live) {
-        float a[HDIM];
+    {   // thread = key j (= i)
+        float k[HDIM], v[HDIM], ak[HDIM], av[HDIM];
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) a[d] = 0.0f;
+        for (int d = 0; d < HDIM; ++d) { k[d] = Ks[i * HDIM + d]; v[d] = Vs[i * HDIM + d]; ak[d] = 0.0f; av[d] = 0.0f; }
         for (int t = 0; t < n; ++t) {
-            const float ds = Pb[(long)t * n + i];
-#pragma unroll
-            for (int d = 0; d < HDIM; ++d) a[d] = fmaf(ds, Qs[t * HDIM + d], a[d]);
+            const float p = expf(dot16(k, Qs + t * HDIM) / 4.0f - Mx[t]) * Inv[t];
+            const float ds = p * (dot16(v, Gs + t * HDIM) - Dt[t]) / 4.0f;
+            axpy16(av, p, Gs + t * HDIM);
+            axpy16(ak, ds, Qs + t * HDIM);
         }
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) dK[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
+        for (int d = 0; d < HDIM; ++d) {
+            dK[(tok0 + i) * D_MODEL + hd * HDIM + d] = ak[d];
+            dV[(tok0 + i) * D_MODEL + hd * HDIM + d] = av[d];
+        }
     }
 }
 
@@ -441,11 +453,11 @@ extern "C" int dgl_adam_step(float *params, const float *grads, float *exp_avg, 
 // ----------------------------------------------------------------------- orchestration
 // Workspace (floats), M = R*n tokens:
 //   T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | E [M][128] (encoder output before the
-//   anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], P [R][8][n][n]
+//   anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row statistics [R][8][n][2]
 //   | backward scratch: dA dB dQ dK dV [M][128] each, dH [M][512]
 static size_t ws_floats(int R, int n) {
     const size_t M = (size_t)R * n;
-    const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * n;
+    const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * 2;
     return M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM;
 }
 extern "C" int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n) { return (int64_t)ws_floats(R, n); }
@@ -474,7 +486,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     hipStream_t s = (hipStream_t)stream;
     const int R = io->R, n = io->n, F = io->problem == DGL_PROBLEM_TSP ? 7 : 9;
     const int M = R * n;
-    const size_t MD = (size_t)M * D_MODEL, MF = (size_t)M * FF_DIM, PP = (size_t)R * HEADS * n * n;
+    const size_t MD = (size_t)M * D_MODEL, MF = (size_t)M * FF_DIM, PP = (size_t)R * HEADS * n * 2;
     float *T = ws;
     float *X[5];
     float *p = T + (size_t)M * DGL_TILE_STRIDE;
@@ -494,9 +506,9 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     const int anchor0 = io->k_last, anchor1 = n - 1;
     const bool cvrp = io->problem == DGL_PROBLEM_CVRP;
     const int n_anchor = cvrp ? 2 : 1;
-    const size_t attn_lds = (size_t)2 * n * HDIM * sizeof(float), attn_bwd_lds = 2 * attn_lds;
+    const size_t attn_lds = (size_t)2 * n * HDIM * sizeof(float), attn_bwd_lds = 2 * attn_lds + (size_t)3 * n * sizeof(float);
     if (attn_bwd_lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
 
     // ---- forward
     hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
@@ -544,7 +556,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         linear_bwd_w(s, dA, D_MODEL, AO[l], D_MODEL, (float *)g.wc, M, D_MODEL, D_MODEL);
         bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)g.bc);
         linear_bwd_x(s, dA, D_MODEL, k.wc, dB, D_MODEL, M, D_MODEL, D_MODEL, false);       // dB = dAO
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS), dim3(256), attn_bwd_lds, s, Qb[l], Kb[l], Vb[l], dB, n, P[l], dQ,
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS), dim3(256), attn_bwd_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n, P[l], dQ,
                            dK, dV);
         // dXin = dA + dQ Wq + dK Wk + dV Wv
         linear_bwd_w(s, dQ, D_MODEL, Xin, D_MODEL, (float *)g.wq, M, D_MODEL, D_MODEL);
