@@ -18,7 +18,7 @@
 // ------------------------------------------------------------------------------- GEMM
 // C[i][j] (op)= sum_kk A(i,kk) B(kk,j),  A(i,kk) = A[i*sai + kk*sak],  B(kk,j) = B[kk*sbk + j*sbn],
 // i < I, j < J, kk in the z-th chunk of [0, KK).  64x64 output tile per workgroup (4 waves, each a
-// 32x32 MFMA tile), K staged through LDS 16 at a time.
+// 32x32 MFMA tile), K staged through LDS 32 at a time.
 //   mode 0: C = acc (+ bias[j]) (ReLU) (+ add[i][j]);  mode 1: C += acc;  mode 2: atomicAdd(C, acc)
 struct GemmArgs {
     const float *A, *B;
@@ -30,44 +30,82 @@ struct GemmArgs {
     int mode, relu, kchunk;
 };
 
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[64][17], Bs[64][17];
+#define GBK 32      // K-extent of one LDS stage
+
+// four consecutive elements of a strided operand tile, along k (k_fast) or along the tile's row index m:
+// one 16-byte load where the four exist and are aligned, guarded scalars otherwise
+__device__ __forceinline__ float4 gemm_load4(const float *__restrict__ P, long sm, long sk, bool k_fast, bool vec_ok,
+                                             int m, int k, int m_hi, int k_hi) {
+    float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (m >= m_hi || k >= k_hi) return v;
+    const float *p = P + (long)m * sm + (long)k * sk;
+    const int left = k_fast ? k_hi - k : m_hi - m;
+    const long step = k_fast ? sk : sm;                       // 1 on the fast index
+    if (vec_ok && left >= 4) return *reinterpret_cast<const float4 *>(p);
+    v.x = p[0];
+    if (left > 1) v.y = p[step];
+    if (left > 2) v.z = p[2 * step];
+    if (left > 3) v.w = p[3 * step];
+    return v;
+}
+
+// Several independent products share one launch: workgroup `blockIdx.x` belongs to the product whose block
+// range [first[b], first[b+1]) contains it.
+#define GEMM_BATCH_MAX 6
+struct GemmBatch {
+    GemmArgs g[GEMM_BATCH_MAX];
+    int first[GEMM_BATCH_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
+    __shared__ float As[64][GBK + 1], Bs[64][GBK + 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const int k_lo = blockIdx.z * g.kchunk, k_hi = min(g.KK, k_lo + g.kchunk);
+    int b = 0;
+    while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
+    const GemmArgs g = batch.g[b];
+    const int local = blockIdx.x - batch.first[b];
+    const int gx = (g.I + 63) / 64, gy = (g.J + 63) / 64;
+    const int i0 = (local % gx) * 64, j0 = ((local / gx) % gy) * 64;
+    const int k_lo = (local / (gx * gy)) * g.kchunk, k_hi = min(g.KK, k_lo + g.kchunk);
     const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
     f32x16 acc = zero16();
-    // staging map: whichever index is contiguous in memory runs fastest across threads; the next K-chunk is
-    // fetched into registers while the MFMAs of the current one run
+    // staging map: each thread moves two groups of four elements per operand and stage; the four run along
+    // whichever index is contiguous in memory.  The next stage is fetched into registers while the MFMAs of the
+    // current one run.
     const bool a_k_fast = g.sak == 1, b_k_fast = g.sbk == 1;
-    int ai[4], ak[4], bj[4], bk[4];
+    const bool a_vec = ((reinterpret_cast<size_t>(g.A) & 15) == 0) && (((a_k_fast ? g.sai : g.sak) & 3) == 0);
+    const bool b_vec = ((reinterpret_cast<size_t>(g.B) & 15) == 0) && (((b_k_fast ? g.sbn : g.sbk) & 3) == 0);
+    int am[2], ak[2], bm[2], bk[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
         const int o = tid + 256 * e;
-        if (a_k_fast) { ak[e] = o & 15; ai[e] = o >> 4; } else { ai[e] = o & 63; ak[e] = o >> 6; }
-        if (b_k_fast) { bk[e] = o & 15; bj[e] = o >> 4; } else { bj[e] = o & 63; bk[e] = o >> 6; }
+        if (a_k_fast) { am[e] = o >> 3; ak[e] = (o & 7) * 4; } else { ak[e] = o >> 4; am[e] = (o & 15) * 4; }
+        if (b_k_fast) { bm[e] = o >> 3; bk[e] = (o & 7) * 4; } else { bk[e] = o >> 4; bm[e] = (o & 15) * 4; }
     }
-    float ra[4], rb[4];
+    float4 ra[2], rb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool av = (i0 + ai[e]) < g.I && (k0 + ak[e]) < k_hi;
-            const bool bv = (j0 + bj[e]) < g.J && (k0 + bk[e]) < k_hi;
-            ra[e] = av ? g.A[(long)(i0 + ai[e]) * g.sai + (long)(k0 + ak[e]) * g.sak] : 0.0f;
-            rb[e] = bv ? g.B[(long)(k0 + bk[e]) * g.sbk + (long)(j0 + bj[e]) * g.sbn] : 0.0f;
+        for (int e = 0; e < 2; ++e) {
+            ra[e] = gemm_load4(g.A, g.sai, g.sak, a_k_fast, a_vec, i0 + am[e], k0 + ak[e], g.I, k_hi);
+            rb[e] = gemm_load4(g.B, g.sbn, g.sbk, b_k_fast, b_vec, j0 + bm[e], k0 + bk[e], g.J, k_hi);
         }
     };
+    auto stage = [&](float (&S)[64][GBK + 1], bool k_fast, int m, int k, const float4 &v) {
+        if (k_fast) { S[m][k] = v.x; S[m][k + 1] = v.y; S[m][k + 2] = v.z; S[m][k + 3] = v.w; }
+        else { S[m][k] = v.x; S[m + 1][k] = v.y; S[m + 2][k] = v.z; S[m + 3][k] = v.w; }
+    };
     fetch(k_lo);
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            As[ai[e]][ak[e]] = ra[e];
-            Bs[bj[e]][bk[e]] = rb[e];
+        for (int e = 0; e < 2; ++e) {
+            stage(As, a_k_fast, am[e], ak[e], ra[e]);
+            stage(Bs, b_k_fast, bm[e], bk[e], rb[e]);
         }
         __syncthreads();
-        if (k0 + 16 < k_hi) fetch(k0 + 16);
+        if (k0 + GBK < k_hi) fetch(k0 + GBK);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc = MFMA32(As[wi + q][2 * t + h], Bs[wj + q][2 * t + h], acc);
+        for (int t = 0; t < GBK / 2; ++t) acc = MFMA32(As[wi + q][2 * t + h], Bs[wj + q][2 * t + h], acc);
         __syncthreads();
     }
     const int j = j0 + wj + q;
@@ -91,39 +129,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-static void launch_gemm(hipStream_t s, const GemmArgs &g) {
-    const int zs = (g.KK + g.kchunk - 1) / g.kchunk;
-    hipLaunchKernelGGL(gemm_kernel, dim3((g.I + 63) / 64, (g.J + 63) / 64, zs), dim3(256), 0, s, g);
-}
+struct GemmLaunch {
+    GemmBatch b;
+    int blocks = 0;
+    GemmLaunch() { b.count = 0; }
+    GemmLaunch &add(const GemmArgs &g) {
+        const int zs = (g.KK + g.kchunk - 1) / g.kchunk;
+        b.g[b.count] = g;
+        b.first[b.count++] = blocks;
+        blocks += ((g.I + 63) / 64) * ((g.J + 63) / 64) * zs;
+        return *this;
+    }
+    void run(hipStream_t s) {
+        b.first[b.count] = blocks;
+        hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), 0, s, b);
+    }
+};
 // Y[M][N] = X[M][K] W[N][K]^T + b (ReLU) (+ add)
-static void linear_fwd(hipStream_t s, const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M,
-                       int N, int K, bool relu, const float *add, int ldadd) {
-    GemmArgs g{X, W, Y, b, add, M, N, K, ldx, 1, 1, K, ldy, ldadd, 0, relu ? 1 : 0, K};
-    launch_gemm(s, g);
+static GemmArgs linear_fwd(const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N, int K,
+                           bool relu, const float *add, int ldadd) {
+    return GemmArgs{X, W, Y, b, add, M, N, K, ldx, 1, 1, K, ldy, ldadd, 0, relu ? 1 : 0, K};
 }
-// dX[M][K] (+)= dY[M][N] W[N][K]
-static void linear_bwd_x(hipStream_t s, const float *dY, int ldy, const float *W, float *dX, int ldx, int M, int N, int K,
-                         bool accumulate) {
-    GemmArgs g{dY, W, dX, nullptr, nullptr, M, K, N, ldy, 1, K, 1, ldx, 0, accumulate ? 1 : 0, 0, N};
-    launch_gemm(s, g);
+// dX[M][K] (+)= dY[M][N] W[N][K]; mode 0 store, 1 add in place (no other writer of dX in flight), 2 atomic add
+static GemmArgs linear_bwd_x(const float *dY, int ldy, const float *W, float *dX, int ldx, int M, int N, int K, int mode) {
+    return GemmArgs{dY, W, dX, nullptr, nullptr, M, K, N, ldy, 1, K, 1, ldx, 0, mode, 0, N};
 }
 // dW[N][K] += dY[M][N]^T X[M][K]   (atomics over chunks of M)
-static void linear_bwd_w(hipStream_t s, const float *dY, int ldy, const float *X, int ldx, float *dW, int M, int N, int K) {
-    GemmArgs g{dY, X, dW, nullptr, nullptr, N, K, M, 1, ldy, ldx, 1, K, 0, 2, 0, 512};
-    launch_gemm(s, g);
+static GemmArgs linear_bwd_w(const float *dY, int ldy, const float *X, int ldx, float *dW, int M, int N, int K) {
+    return GemmArgs{dY, X, dW, nullptr, nullptr, N, K, M, 1, ldy, ldx, 1, K, 0, 2, 0, 512};
 }
 
-// db[j] += sum_i dY[i][j]
-__global__ void colsum_kernel(const float *__restrict__ dY, int ld, int M, int N, float *__restrict__ db) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const int i_lo = blockIdx.y * 128, i_hi = min(M, i_lo + 128);
+// db[j] += sum_i dY[i][j]: a workgroup sums 32 rows (thread = column, 4 row groups of 8, LDS reduction)
+__global__ __launch_bounds__(512) void colsum_kernel(const float *__restrict__ dY, int ld, int M, int N, float *__restrict__ db) {
+    __shared__ float part[4][128];
+    const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int j = blockIdx.x * 128 + c;
+    const int i_lo = blockIdx.y * 32 + grp * 8, i_hi = min(M, i_lo + 8);
     float s = 0.0f;
-    for (int i = i_lo; i < i_hi; ++i) s += dY[(long)i * ld + j];
-    atomicAdd(db + j, s);
+    if (j < N)
+        for (int i = i_lo; i < i_hi; ++i) s += dY[(long)i * ld + j];
+    part[grp][c] = s;
+    __syncthreads();
+    if (grp == 0 && j < N) atomicAdd(db + j, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
 }
 static void bias_bwd(hipStream_t s, const float *dY, int ld, int M, int N, float *db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, (M + 127) / 128), dim3(128), 0, s, dY, ld, M, N, db);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(512), 0, s, dY, ld, M, N, db);
 }
 
 // dH *= (H > 0)
@@ -294,24 +344,22 @@ __global__ __launch_bounds__(128) void anchor_fwd_kernel(const float *__restrict
     for (int k = 0; k < D_MODEL; ++k) s = fmaf(W[c * D_MODEL + k], xs[k], s);
     Y[tk * D_MODEL + c] = s + b[c];
 }
-// dX = dY except at the anchors, where dX_anchor = W_a^T dY_anchor; dW_a += dY_anchor x_anchor^T; db_a += dY_anchor
+// dX = dY except at the anchors, where dX_anchor = W_a^T dY_anchor; db_a += dY_anchor
+// (dW_a += dY_anchor x_anchor^T runs before this kernel as a strided GEMM over the rows' anchor tokens)
 __global__ __launch_bounds__(128) void anchor_bwd_kernel(const float *__restrict__ X, float *__restrict__ dY, int n, int tok0_,
                                                          int tok1_, const float *__restrict__ W0, const float *__restrict__ W1,
-                                                         float *__restrict__ dW0, float *__restrict__ db0,
-                                                         float *__restrict__ dW1, float *__restrict__ db1) {
-    __shared__ float xs[D_MODEL], gs[D_MODEL];
+                                                         float *__restrict__ db0, float *__restrict__ db1) {
+    __shared__ float gs[D_MODEL];
     const int r = blockIdx.x, a = blockIdx.y, c = threadIdx.x;
     const long tk = (long)r * n + (a == 0 ? tok0_ : tok1_);
     const float *W = a == 0 ? W0 : W1;
-    float *dW = a == 0 ? dW0 : dW1, *db = a == 0 ? db0 : db1;
-    xs[c] = X[tk * D_MODEL + c];
+    float *db = a == 0 ? db0 : db1;
     gs[c] = dY[tk * D_MODEL + c];
     __syncthreads();
     float s = 0.0f;
     for (int o = 0; o < D_MODEL; ++o) s = fmaf(W[o * D_MODEL + c], gs[o], s);
     dY[tk * D_MODEL + c] = s;                                     // becomes dX in place
     atomicAdd(db + c, gs[c]);
-    for (int k = 0; k < D_MODEL; ++k) atomicAdd(dW + c * D_MODEL + k, gs[c] * xs[k]);
 }
 
 // -------------------------------------------------------------------------- output stage
@@ -513,7 +561,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     // ---- forward
     hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
                        io->tile_row_stride, R, n, T);
-    linear_fwd(s, T, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], D_MODEL, M, D_MODEL, F, false, nullptr, 0);
+    GemmLaunch().add(linear_fwd(T, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], D_MODEL, M, D_MODEL, F, false, nullptr, 0)).run(s);
     for (int l = 0; l < 4; ++l) {
         const dgl_block_weights_t &k = w->block[l];
         const float *Xin = X[l];
@@ -523,13 +571,15 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, X[1], n, anchor0, anchor1,
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0]);
         }
-        linear_fwd(s, Xin, D_MODEL, k.wq, nullptr, Qb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0);
-        linear_fwd(s, Xin, D_MODEL, k.wk, nullptr, Kb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0);
-        linear_fwd(s, Xin, D_MODEL, k.wv, nullptr, Vb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0);
+        GemmLaunch()
+            .add(linear_fwd(Xin, D_MODEL, k.wq, nullptr, Qb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, D_MODEL, k.wk, nullptr, Kb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, D_MODEL, k.wv, nullptr, Vb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .run(s);
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(256), attn_lds, s, Qb[l], Kb[l], Vb[l], n, P[l], AO[l]);
-        linear_fwd(s, AO[l], D_MODEL, k.wc, k.bc, O1[l], D_MODEL, M, D_MODEL, D_MODEL, false, Xin, D_MODEL);
-        linear_fwd(s, O1[l], D_MODEL, k.w1, k.b1, H[l], FF_DIM, M, FF_DIM, D_MODEL, true, nullptr, 0);
-        linear_fwd(s, H[l], FF_DIM, k.w2, k.b2, X[l + 1], D_MODEL, M, D_MODEL, FF_DIM, false, O1[l], D_MODEL);
+        GemmLaunch().add(linear_fwd(AO[l], D_MODEL, k.wc, k.bc, O1[l], D_MODEL, M, D_MODEL, D_MODEL, false, Xin, D_MODEL)).run(s);
+        GemmLaunch().add(linear_fwd(O1[l], D_MODEL, k.w1, k.b1, H[l], FF_DIM, M, FF_DIM, D_MODEL, true, nullptr, 0)).run(s);
+        GemmLaunch().add(linear_fwd(H[l], FF_DIM, k.w2, k.b2, X[l + 1], D_MODEL, M, D_MODEL, FF_DIM, false, O1[l], D_MODEL)).run(s);
     }
     const bool train = grad != nullptr;
     hipLaunchKernelGGL(output_kernel, dim3(R), dim3(64), (size_t)n * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
@@ -543,35 +593,52 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         const dgl_block_weights_t &k = w->block[l];
         const dgl_block_weights_t &g = grad->block[l];
         const float *Xin = X[l];
+        // Products that share no output run in one launch each.
         // X[l+1] = O1 + W2 H + b2
-        linear_bwd_w(s, dA, D_MODEL, H[l], FF_DIM, (float *)g.w2, M, D_MODEL, FF_DIM);
         bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)g.b2);
-        linear_bwd_x(s, dA, D_MODEL, k.w2, dH, FF_DIM, M, D_MODEL, FF_DIM, false);
+        GemmLaunch()
+            .add(linear_bwd_w(dA, D_MODEL, H[l], FF_DIM, (float *)g.w2, M, D_MODEL, FF_DIM))
+            .add(linear_bwd_x(dA, D_MODEL, k.w2, dH, FF_DIM, M, D_MODEL, FF_DIM, 0))
+            .run(s);
         hipLaunchKernelGGL(relu_bwd_kernel, dim3(2048), dim3(256), 0, s, dH, H[l], (long)MF);
         // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1   (accumulated into dA)
-        linear_bwd_w(s, dH, FF_DIM, O1[l], D_MODEL, (float *)g.w1, M, FF_DIM, D_MODEL);
         bias_bwd(s, dH, FF_DIM, M, FF_DIM, (float *)g.b1);
-        linear_bwd_x(s, dH, FF_DIM, k.w1, dA, D_MODEL, M, FF_DIM, D_MODEL, true);
+        GemmLaunch()
+            .add(linear_bwd_w(dH, FF_DIM, O1[l], D_MODEL, (float *)g.w1, M, FF_DIM, D_MODEL))
+            .add(linear_bwd_x(dH, FF_DIM, k.w1, dA, D_MODEL, M, FF_DIM, D_MODEL, 1))
+            .run(s);
         // O1 = Xin + Wc AO + bc
-        linear_bwd_w(s, dA, D_MODEL, AO[l], D_MODEL, (float *)g.wc, M, D_MODEL, D_MODEL);
         bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)g.bc);
-        linear_bwd_x(s, dA, D_MODEL, k.wc, dB, D_MODEL, M, D_MODEL, D_MODEL, false);       // dB = dAO
+        GemmLaunch()
+            .add(linear_bwd_w(dA, D_MODEL, AO[l], D_MODEL, (float *)g.wc, M, D_MODEL, D_MODEL))
+            .add(linear_bwd_x(dA, D_MODEL, k.wc, dB, D_MODEL, M, D_MODEL, D_MODEL, 0))       // dB = dAO
+            .run(s);
         hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS), dim3(256), attn_bwd_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n, P[l], dQ,
                            dK, dV);
-        // dXin = dA + dQ Wq + dK Wk + dV Wv
-        linear_bwd_w(s, dQ, D_MODEL, Xin, D_MODEL, (float *)g.wq, M, D_MODEL, D_MODEL);
-        linear_bwd_w(s, dK, D_MODEL, Xin, D_MODEL, (float *)g.wk, M, D_MODEL, D_MODEL);
-        linear_bwd_w(s, dV, D_MODEL, Xin, D_MODEL, (float *)g.wv, M, D_MODEL, D_MODEL);
-        linear_bwd_x(s, dQ, D_MODEL, k.wq, dA, D_MODEL, M, D_MODEL, D_MODEL, true);
-        linear_bwd_x(s, dK, D_MODEL, k.wk, dA, D_MODEL, M, D_MODEL, D_MODEL, true);
-        linear_bwd_x(s, dV, D_MODEL, k.wv, dA, D_MODEL, M, D_MODEL, D_MODEL, true);
-        if (l == 1)
+        // dXin = dA + dQ Wq + dK Wk + dV Wv: three products into one output, added atomically
+        GemmLaunch()
+            .add(linear_bwd_w(dQ, D_MODEL, Xin, D_MODEL, (float *)g.wq, M, D_MODEL, D_MODEL))
+            .add(linear_bwd_w(dK, D_MODEL, Xin, D_MODEL, (float *)g.wk, M, D_MODEL, D_MODEL))
+            .add(linear_bwd_w(dV, D_MODEL, Xin, D_MODEL, (float *)g.wv, M, D_MODEL, D_MODEL))
+            .add(linear_bwd_x(dQ, D_MODEL, k.wq, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
+            .add(linear_bwd_x(dK, D_MODEL, k.wk, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
+            .add(linear_bwd_x(dV, D_MODEL, k.wv, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
+            .run(s);
+        if (l == 1) {
+            // dW_a[c][k] += sum_r dA[anchor of row r][c] E[anchor of row r][k]: the rows' anchor tokens are n tokens apart
+            GemmLaunch gl;
+            for (int a = 0; a < n_anchor; ++a) {
+                const long off = (long)(a == 0 ? anchor0 : anchor1) * D_MODEL;
+                gl.add(GemmArgs{dA + off, E + off, (float *)grad->anchor_w[a], nullptr, nullptr, D_MODEL, D_MODEL, R, 1,
+                                (long)n * D_MODEL, (long)n * D_MODEL, 1, D_MODEL, 0, 2, 0, 512});
+            }
+            gl.run(s);
             hipLaunchKernelGGL(anchor_bwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, dA, n, anchor0, anchor1, w->anchor_w[0],
-                               w->anchor_w[cvrp ? 1 : 0], (float *)grad->anchor_w[0], (float *)grad->anchor_b[0],
-                               (float *)grad->anchor_w[cvrp ? 1 : 0], (float *)grad->anchor_b[cvrp ? 1 : 0]);
+                               w->anchor_w[cvrp ? 1 : 0], (float *)grad->anchor_b[0], (float *)grad->anchor_b[cvrp ? 1 : 0]);
+        }
     }
     // X[0] = T We^T + be
-    linear_bwd_w(s, dA, D_MODEL, T, DGL_TILE_STRIDE, (float *)grad->emb_w, M, D_MODEL, F);
+    GemmLaunch().add(linear_bwd_w(dA, D_MODEL, T, DGL_TILE_STRIDE, (float *)grad->emb_w, M, D_MODEL, F)).run(s);
     bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)grad->emb_b);
     DGL_CHECK_LAUNCH("dgl_policy_general (backward)");
     return DGL_OK;
