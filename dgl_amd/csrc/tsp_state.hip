@@ -77,12 +77,6 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     TspRowCtx cx;
     cx.xyb = st.xy + (size_t)b * N * 2;
     cx.rowN = (size_t)r * N;
-    // wave-uniform values: kept in scalar registers
-    const int cur = __builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]);
-    const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(st.tour[cx.rowN]);
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
-    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
-
     const int u = N - t;                                    // unvisited after this step
     const float up1 = (float)(u + 1);
     const DglConstDiv du = dgl_const_div((float)u);
@@ -108,6 +102,12 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     };
     Group nxt;
     request(j_begin, nxt);
+    // The current node and its coordinates are two dependent round trips; they start only now, behind the first
+    // group's loads, which do not depend on them.  Wave-uniform values: kept in scalar registers.
+    const int cur = __builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]);
+    const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(st.tour[cx.rowN]);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
+    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
     // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
     unsigned long long vis_words = 0;

@@ -1,0 +1,29 @@
+"""Step kernel at a saturating batch: state update alone (no neighbourhood requested) vs the whole step."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from dgl_amd import _lib
+from dgl_amd._lib import check, ptr, stream_ptr
+from dgl_amd.engine import TspEngine
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+N, knn, iters = 1000, 30, 30
+dev = torch.device('cuda:0')
+eng = TspEngine(torch.rand(R, N, 2, device=dev), 1, knn)
+lib = _lib.load()
+eng.reset()
+sels = [torch.randint(0, N, (R,), dtype=torch.int32, device=dev) for _ in range(2 * iters + 6)]
+def run(full, base):
+    st = eng.state["struct"]
+    for i in range(iters + 3):
+        if i == 3:
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        eng.t += 1
+        check(lib.dgl_tsp_step(ctypes.byref(st), ptr(sels[base + i]), eng.t, knn, ptr(eng.idx) if full else 0,
+                               ptr(eng.tile) if full else 0, stream_ptr()), "step")
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+for full in (False, True, False, True):
+    ms = run(full, 0 if not full else iters + 3)
+    by = (24 * N + N / 8 + (8 * knn if full else 0)) * R
+    print(f"R={R} {'whole step' if full else 'state update only'}: {ms*1e3:.1f} us, {by/ms/1e6:.0f} GB/s")
