@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="instances per GPU")
     ap.add_argument("--knn", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="instances decoded by the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="instances decoded by the CPU baseline")
     ap.add_argument("--no-aux", action="store_true", help="skip the saturating-batch kNN measurement")
     args = ap.parse_args()
 
