@@ -93,7 +93,7 @@ def test_state_data_matches_golden(name, device):
             data = eng.data().cpu().numpy()
             g = case[f"snap{t}/data"]
             u = eng.N - t
-            # running features amplify a 1-ulp start difference by ~N/u (see DESIGN.md)
+            # running features amplify a 1-ulp start difference by ~N/u
             tol = 4e-7 * eng.N / u
             np.testing.assert_allclose(data[:, :, :3], g[:, :, :3], rtol=2e-7, atol=1e-7)
             np.testing.assert_allclose(data[:, :, 3:5], g[:, :, 3:5], rtol=tol, atol=tol)
