@@ -247,19 +247,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__
     float q[HDIM];
 #pragma unroll
     for (int d = 0; d < HDIM; ++d) q[d] = Q[(tok0 + i) * D_MODEL + hd * HDIM + d];
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) mx = fmaxf(mx, dot16(q, Ks + j * HDIM) / 4.0f);
-    float sum = 0.0f;
-    for (int j = 0; j < n; ++j) sum += expf(dot16(q, Ks + j * HDIM) / 4.0f - mx);
+    // One pass over the keys with a running maximum: whenever it grows, the sum and the output accumulated so
+    // far are rescaled (exp(old - new) <= 1).  Equal to softmax(s) V up to rounding.
+    float mx = -INFINITY, sum = 0.0f;
     float o[HDIM];
 #pragma unroll
     for (int d = 0; d < HDIM; ++d) o[d] = 0.0f;
     for (int j = 0; j < n; ++j) {
-        const float p = expf(dot16(q, Ks + j * HDIM) / 4.0f - mx) / sum;
+        const float sc = dot16(q, Ks + j * HDIM) / 4.0f;
+        if (sc > mx) {
+            const float f = expf(mx - sc);          // 0 on the first key (mx = -inf)
+            sum *= f;
+#pragma unroll
+            for (int d = 0; d < HDIM; ++d) o[d] *= f;
+            mx = sc;
+        }
+        const float p = expf(sc - mx);
+        sum += p;
         axpy16(o, p, Vs + j * HDIM);
     }
+    const float inv = 1.0f / sum;
 #pragma unroll
-    for (int d = 0; d < HDIM; ++d) O[(tok0 + i) * D_MODEL + hd * HDIM + d] = o[d];
+    for (int d = 0; d < HDIM; ++d) O[(tok0 + i) * D_MODEL + hd * HDIM + d] = o[d] * inv;
     float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
     st[0] = mx;
     st[1] = sum;
