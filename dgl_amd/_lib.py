@@ -59,6 +59,9 @@ SIGNATURES = {
     "dgl_tsp_step": (c_int32, [POINTER(TspState), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dgl_tsp_knn": (c_int32, [POINTER(TspState), c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dgl_tsp_state_data": (c_int32, [POINTER(TspState), c_int32, c_void_p, c_void_p]),
+    "dgl_tsp_step_beam": (c_int32, [POINTER(TspState), POINTER(TspState), c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dgl_tsp_beam_backtrack": (c_int32, [POINTER(TspState), c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dgl_tsp_tour_length": (c_int32, [POINTER(TspState), c_void_p, c_void_p]),
     "dgl_tsp_permute": (c_int32, [POINTER(TspState), POINTER(TspState), c_void_p, c_int32, c_int32, c_void_p]),
     "dgl_cvrp_reset": (c_int32, [POINTER(CvrpState), c_void_p]),

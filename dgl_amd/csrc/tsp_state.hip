@@ -53,10 +53,24 @@ __device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const Ts
 // (state update + keys into the shared LDS array), then wave 0 alone selects and writes the tile.
 // With few rows this is what hides the memory latency of the scan (one wave per row leaves most
 // SIMDs with a single wave and every load exposed).  LDS: the row's arrays + 64 * WAVES lane minima.
+// Beam search: row r of the state being written continues row (r / beam) * beam + prev_k[r] of another copy of the
+// state (its back-pointer).  The step then reads avg / sd / visited of that row and writes row r, which replaces
+// the separate gather of the whole state; the chosen node and the parent row go to a history from which the tours
+// are rebuilt once at the end (tsp_backtrack_kernel).  prev_k == NULL: the ordinary in-place step.
+struct TspBeamLink {
+    const float *avg_in, *sd_in;
+    const uint64_t *vis_in;
+    const int32_t *tour_in;
+    const int32_t *prev_k;
+    int beam;
+    int32_t *hist_node, *hist_parent;      // [N][R], entry (t - 1) * R + r
+};
+
 template <int WAVES, bool UPDATE, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
-                                                             float *__restrict__ tile_out, int lds_per_wave) {
+                                                             float *__restrict__ tile_out, int lds_per_wave,
+                                                             TspBeamLink link) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
@@ -85,6 +99,12 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     uint64_t *vis = st.visited + (size_t)r * W;
     const float2 *xy2 = reinterpret_cast<const float2 *>(cx.xyb);
     float *avg = st.avg + cx.rowN, *sd = st.sd + cx.rowN;
+    const bool linked = UPDATE && link.prev_k != nullptr;
+    int sr = r;                                             // the row this one continues
+    if (linked) sr = (r / link.beam) * link.beam + min(max(__builtin_amdgcn_readfirstlane(link.prev_k[r]), 0), link.beam - 1);
+    const float *avg_in = linked ? link.avg_in + (size_t)sr * N : avg, *sd_in = linked ? link.sd_in + (size_t)sr * N : sd;
+    const uint64_t *vis_in = linked ? link.vis_in + (size_t)sr * W : vis;
+    const int32_t *tour_in = linked ? link.tour_in + (size_t)sr * N : st.tour + cx.rowN;
     // The loads of a group of STEP_UNROLL chunks are issued one group ahead of its arithmetic, so
     // every wave keeps a group of requests in flight while it computes (clamped addresses keep the
     // loads unconditional).
@@ -97,7 +117,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = min(j0 + 64 * q + lane, N - 1);
             g.p[q] = xy2[j];
-            if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
+            if (UPDATE) { g.a0[q] = avg_in[j]; g.s0[q] = sd_in[j]; }
         }
     };
     Group nxt;
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     // The current node and its coordinates are two dependent round trips; they start only now, behind the first
     // group's loads, which do not depend on them.  Wave-uniform values: kept in scalar registers.
     const int cur = __builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]);
-    const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(st.tour[cx.rowN]);
+    const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(tour_in[0]);
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     for (int j0 = j_begin; j0 < j_end; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
-        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
@@ -146,7 +166,14 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         }
     }
     // (a wave that still scans may read the visited word with this bit already set: it excludes `cur` anyway)
-    if (UPDATE && lane == 0 && (!SPLIT || wave == 0)) {
+    if (UPDATE && linked && (!SPLIT || wave == 0)) {
+        for (int w = lane; w < W; w += 64) vis[w] = vis_in[w] | (w == (cur >> 6) ? 1ull << (cur & 63) : 0ull);
+        if (lane == 0) {
+            link.hist_node[(size_t)(t - 1) * st.R + r] = cur;
+            link.hist_parent[(size_t)(t - 1) * st.R + r] = sr;
+            st.tour[cx.rowN] = start;                       // every row of a beam group shares its start node
+        }
+    } else if (UPDATE && lane == 0 && (!SPLIT || wave == 0)) {
         st.tour[cx.rowN + (t - 1)] = cur;
         vis[cur >> 6] |= 1ull << (cur & 63);
     }
@@ -272,7 +299,7 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
 
 template <bool UPDATE>
 static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
-                           float *tile_out, dgl_stream_t stream, const char *what) {
+                           float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     const size_t lds_split = (size_t)(per_wave + 256) * sizeof(float);
@@ -285,10 +312,10 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave);
+                           *st, selected, t, knn, idx_out, tile_out, per_wave, link);
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave);
+                           *st, selected, t, knn, idx_out, tile_out, per_wave, link);
     } else {
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
@@ -296,7 +323,7 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1, UPDATE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         hipLaunchKernelGGL((tsp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
-                           selected, t, knn, idx_out, tile_out, per_wave);
+                           selected, t, knn, idx_out, tile_out, per_wave, link);
     }
     DGL_CHECK_LAUNCH(what);
     return DGL_OK;
@@ -311,6 +338,48 @@ extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, 
     DGL_CHECK_ARG(idx_out == nullptr || knn >= 1, "knn=%d must be >= 1", knn);
     if (idx_out == nullptr) knn = 1;
     return launch_tsp_step<true>(st, selected, t, knn, idx_out, tile_out, stream, "dgl_tsp_step");
+}
+
+extern "C" int dgl_tsp_step_beam(const dgl_tsp_state_t *src, const dgl_tsp_state_t *dst, const int32_t *prev_k,
+                                 int32_t beam, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                                 float *tile_out, int32_t *hist_node, int32_t *hist_parent, dgl_stream_t stream) {
+    if (int e = check_tsp_state(src)) return e;
+    if (int e = check_tsp_state(dst)) return e;
+    DGL_CHECK_ARG(selected != nullptr && prev_k != nullptr && hist_node != nullptr && hist_parent != nullptr, "NULL argument");
+    DGL_CHECK_ARG(beam >= 1 && src->R == dst->R && src->N == dst->N && src->R % beam == 0 && src->xy == dst->xy,
+                  "src/dst shapes differ or R %% beam != 0");
+    DGL_CHECK_ARG(src->avg != dst->avg && src->sd != dst->sd && src->visited != dst->visited && src->tour != dst->tour,
+                  "src and dst must be different buffers");
+    DGL_CHECK_ARG(t >= 2 && t <= dst->N, "t=%d outside [2,N=%d] (the first step has no back-pointer)", t, dst->N);
+    DGL_CHECK_ARG((idx_out == nullptr) == (tile_out == nullptr), "idx_out and tile_out must both be given or both be NULL");
+    DGL_CHECK_ARG(idx_out == nullptr || knn >= 1, "knn=%d must be >= 1", knn);
+    if (idx_out == nullptr) knn = 1;
+    const TspBeamLink link{src->avg, src->sd, src->visited, src->tour, prev_k, beam, hist_node, hist_parent};
+    return launch_tsp_step<true>(dst, selected, t, knn, idx_out, tile_out, stream, "dgl_tsp_step_beam", link);
+}
+
+// tour[r][t - 1] for t = t_last .. t_first from the history of linked steps: one thread walks one row's back-pointers
+__global__ void tsp_backtrack_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ hist_node,
+                                     const int32_t *__restrict__ hist_parent, int t_first, int t_last) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= st.R) return;
+    int p = r;
+    for (int t = t_last; t >= t_first; --t) {
+        const size_t e = (size_t)(t - 1) * st.R + p;
+        st.tour[(size_t)r * st.N + (t - 1)] = hist_node[e];
+        p = min(max(hist_parent[e], 0), st.R - 1);
+    }
+}
+
+extern "C" int dgl_tsp_beam_backtrack(const dgl_tsp_state_t *st, const int32_t *hist_node, const int32_t *hist_parent,
+                                      int32_t t_first, int32_t t_last, dgl_stream_t stream) {
+    if (int e = check_tsp_state(st)) return e;
+    DGL_CHECK_ARG(hist_node != nullptr && hist_parent != nullptr, "NULL history");
+    DGL_CHECK_ARG(t_first >= 2 && t_last <= st->N && t_first <= t_last, "steps [%d,%d] outside [2,N=%d]", t_first, t_last, st->N);
+    hipLaunchKernelGGL(tsp_backtrack_kernel, dim3((st->R + 63) / 64), dim3(64), 0, (hipStream_t)stream, *st, hist_node,
+                       hist_parent, t_first, t_last);
+    DGL_CHECK_LAUNCH("dgl_tsp_beam_backtrack");
+    return DGL_OK;
 }
 
 extern "C" int dgl_tsp_knn(const dgl_tsp_state_t *st, int32_t t, int32_t knn, int32_t *idx_out, float *tile_out,

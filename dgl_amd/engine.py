@@ -245,10 +245,33 @@ class TspEngine:
                                                 self.N, step, ptr(prev_k), ptr(action), stream_ptr()),
               "dgl_beam_advance_compact")
 
+    def step_beam(self, prev_k: torch.Tensor, selected: torch.Tensor, beam: int) -> None:
+        """Back-pointer gather and step in one pass over the state (other buffer <- this buffer); the tours are
+        rebuilt from the history by ``backtrack``."""
+        assert len(self.bufs) == 2 and prev_k.dtype == torch.int32 and selected.dtype == torch.int32
+        if getattr(self, "hist_node", None) is None:
+            self.hist_node = torch.zeros(self.N, self.R, dtype=torch.int32, device=self.device)
+            self.hist_parent = torch.zeros(self.N, self.R, dtype=torch.int32, device=self.device)
+        src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
+        self.t += 1
+        more = self.t < self.N
+        check(self.lib.dgl_tsp_step_beam(ctypes.byref(src["struct"]), ctypes.byref(dst["struct"]), ptr(prev_k), beam,
+                                         ptr(selected), self.t, self.knn, ptr(self.idx) if more else 0,
+                                         ptr(self.tile) if more else 0, ptr(self.hist_node), ptr(self.hist_parent),
+                                         stream_ptr()), "dgl_tsp_step_beam")
+        self.cur = 1 - self.cur
+        if more:
+            self.tile_t = self.t
+
+    def backtrack(self, t_first: int) -> None:
+        check(self.lib.dgl_tsp_beam_backtrack(ctypes.byref(self.state["struct"]), ptr(self.hist_node),
+                                              ptr(self.hist_parent), t_first, self.t, stream_ptr()),
+              "dgl_tsp_beam_backtrack")
+
     def beam_rollout(self, policy: PackedPolicy, start: torch.Tensor, beam: int) -> torch.Tensor:
-        """Beam-search decode (TSP/TSPTester.py:145-199) on the compact state: per step the policy,
-        the beam expansion over beam*k candidates, the back-pointer permutation and the fused
-        state update; nothing returns to the host."""
+        """Beam-search decode (TSP/TSPTester.py:145-199) on the compact state: per step the policy, the beam
+        expansion over beam*k candidates and one pass over the state that follows the back-pointers while it
+        updates; the tours are rebuilt from the back-pointer history at the end.  Nothing returns to the host."""
         assert self.rpi % beam == 0 and len(self.bufs) == 2
         G = self.R // beam
         dev = self.device
@@ -261,9 +284,10 @@ class TspEngine:
         while self.t < self.N:
             self.forward(policy, want_logits=False, want_selected=False)
             self.beam_advance(scores, beam, step, prev_k, action)
-            self.permute(prev_k, beam)
-            self.step(action.view(-1))
+            self.step_beam(prev_k.view(-1), action.view(-1), beam)
             step += 1
+        if self.N >= 2:
+            self.backtrack(2)
         self.beam_scores = scores
         return self.tour_length()
 

@@ -90,6 +90,19 @@ DGL_API int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream);
 DGL_API int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
                  int32_t *idx_out, float *tile_out, dgl_stream_t stream);
 
+/* Beam-search step without a separate state gather (TSPEnv.perm_attr, TSP/TSPEnv.py:278-308, followed by
+ * TSPEnv.step): row r of `dst` continues row (r / beam) * beam + prev_k[r] of `src` (two copies of the
+ * state over the same instances); avg / sd / visited are read from that row, updated for `selected[r]` and
+ * written to row r of `dst`, the neighbourhood outputs are those of dgl_tsp_step.  Tours are not copied:
+ * the chosen node and the parent row of step t go to hist_node / hist_parent [N][R] (entry (t-1)*R + r) and
+ * dgl_tsp_beam_backtrack rebuilds dst->tour for steps t_first..t_last (2 <= t_first) once at the end;
+ * entry 0 (the start node, shared by a beam group) is kept by every linked step. */
+DGL_API int dgl_tsp_step_beam(const dgl_tsp_state_t *src, const dgl_tsp_state_t *dst, const int32_t *prev_k,
+                              int32_t beam, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                              float *tile_out, int32_t *hist_node, int32_t *hist_parent, dgl_stream_t stream);
+DGL_API int dgl_tsp_beam_backtrack(const dgl_tsp_state_t *st, const int32_t *hist_node, const int32_t *hist_parent,
+                                   int32_t t_first, int32_t t_last, dgl_stream_t stream);
+
 /* TSPModel.get_knn_state/_get_node/_norm_node alone (TSP/TSPModel.py:50-100,141-172): the
  * neighbourhood and token tile of the current node tour[r][t-1] from the state as it stands
  * after t steps, without touching the state.  Same outputs as dgl_tsp_step. */
