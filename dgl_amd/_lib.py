@@ -70,6 +70,9 @@ SIGNATURES = {
     "dgl_cvrp_knn": (c_int32, [POINTER(CvrpState), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
     "dgl_cvrp_state_data": (c_int32, [POINTER(CvrpState), c_int32, c_void_p, c_void_p]),
+    "dgl_cvrp_step_beam": (c_int32, [POINTER(CvrpState), POINTER(CvrpState), c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                     c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dgl_cvrp_beam_backtrack": (c_int32, [POINTER(CvrpState), c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "dgl_cvrp_route_length": (c_int32, [POINTER(CvrpState), c_void_p, c_void_p]),
     "dgl_cvrp_permute": (c_int32, [POINTER(CvrpState), POINTER(CvrpState), c_void_p, c_int32, c_int32, c_void_p]),
     "dgl_policy_packed_floats": (c_int64, [c_int32]),

@@ -68,13 +68,28 @@ __device__ __forceinline__ float cvrp_features(const dgl_cvrp_state_t &st, const
 // One wave per row.  LDS per wave: keysL[M] + keysD[M] + tile[(knn+depot_knn+2)*STRIDE] + scratch[128].
 // SPLIT: the WAVES waves of a workgroup share one row (each scans a contiguous part of the nodes, wave 0
 // selects and writes the tiles), as in tsp_step_kernel.
+// Beam search: row r of the state being written continues row (r / beam) * beam + prev_k[r] of another copy of the
+// state; avg / sd / visited / capacity are read from that row and written to row r.  The action and the parent row
+// go to a history from which nodes and flags are rebuilt at the end (cvrp_backtrack_kernel).  prev_k == NULL: the
+// ordinary in-place step.
+struct CvrpBeamLink {
+    const float *avg_in, *sd_in, *cap_in;
+    const uint64_t *vis_in;
+    const int32_t *nodes_in;
+    const int8_t *flags_in;
+    const int32_t *prev_k;
+    int beam;
+    int32_t *hist_action, *hist_parent;    // [N][R], entry (t - 1) * R + r
+};
+
 template <int WAVES, bool UPDATE, bool D3, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
                                                               int32_t *__restrict__ idx_dep_out,
                                                               uint8_t *__restrict__ infeasible_out,
-                                                              float *__restrict__ tile_out, int lds_per_wave) {
+                                                              float *__restrict__ tile_out, int lds_per_wave,
+                                                              CvrpBeamLink link) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
@@ -102,7 +117,10 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     const bool via = act > N;
     const int cur = UPDATE ? (via ? act - (N + 1) : act) : __builtin_amdgcn_readfirstlane(st.nodes[(size_t)r * N + (t - 1)]);
     const float dem_cur = cx.demb[cur];
-    const float cap_old = st.capacity[r];
+    const bool linked = UPDATE && link.prev_k != nullptr;
+    int sr = r;                                                // the row this one continues
+    if (linked) sr = (r / link.beam) * link.beam + min(max(__builtin_amdgcn_readfirstlane(link.prev_k[r]), 0), link.beam - 1);
+    const float cap_old = linked ? link.cap_in[sr] : st.capacity[r];
     float cap = !UPDATE ? cap_old : (via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur));
     const float cap_eps = __fadd_rn(cap, 0.000001f);          // feasibility uses the un-nudged capacity
 
@@ -117,6 +135,8 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     uint64_t *vis = st.visited + (size_t)r * W;
     const float2 *xy2 = reinterpret_cast<const float2 *>(cx.xyb);
     float *avg = st.avg + cx.rowM, *sd = st.sd + cx.rowM;
+    const float *avg_in = linked ? link.avg_in + (size_t)sr * M : avg, *sd_in = linked ? link.sd_in + (size_t)sr * M : sd;
+    const uint64_t *vis_in = linked ? link.vis_in + (size_t)sr * W : vis;
     // The loads of a group of STEP_UNROLL chunks are issued one group ahead of its arithmetic
     // (clamped addresses keep them unconditional).
     struct Group {
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = min(j0 + 64 * q + lane, M - 1);
             g.p[q] = xy2[j];
-            if (UPDATE) { g.a0[q] = avg[j]; g.s0[q] = sd[j]; }
+            if (UPDATE) { g.a0[q] = avg_in[j]; g.s0[q] = sd_in[j]; }
             g.dm[q] = D3 ? cx.demb[j] : 0.0f;
         }
     };
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     for (int j0 = j_begin; j0 < j_end; j0 += 64 * STEP_UNROLL) {
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
-        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
@@ -186,7 +206,17 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
         // every wave has read the row's capacity; keys, minima and the avg/sd stores of every wave are complete
         __syncthreads();
     }
-    if (lane == 0 && (!SPLIT || wave == 0)) {
+    if (linked && (!SPLIT || wave == 0)) {
+        for (int w = lane; w < W; w += 64) vis[w] = vis_in[w] | (w == (cur >> 6) ? 1ull << (cur & 63) : 0ull);
+        if (lane == 0) {
+            st.capacity[r] = cap;
+            link.hist_action[(size_t)(t - 1) * st.R + r] = act;
+            link.hist_parent[(size_t)(t - 1) * st.R + r] = sr;
+            // every row of a beam group shares its first move
+            st.nodes[(size_t)r * N] = link.nodes_in[(size_t)sr * N];
+            st.flags[(size_t)r * N] = link.flags_in[(size_t)sr * N];
+        }
+    } else if (lane == 0 && (!SPLIT || wave == 0)) {
         st.capacity[r] = cap;
         if (UPDATE) {
             st.nodes[(size_t)r * N + (t - 1)] = cur;
@@ -391,7 +421,7 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
 template <bool UPDATE, bool D3>
 static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
                             int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
-                            dgl_stream_t stream, const char *what) {
+                            dgl_stream_t stream, const char *what, const CvrpBeamLink &link = CvrpBeamLink{}) {
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
@@ -403,11 +433,11 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                           per_wave);
+                           per_wave, link);
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                           per_wave);
+                           per_wave, link);
     } else {
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
@@ -416,7 +446,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
             (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1, UPDATE, D3>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
-                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave);
+                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave, link);
     }
     DGL_CHECK_LAUNCH(what);
     return DGL_OK;
@@ -438,6 +468,61 @@ extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, 
                                             tile_out, stream, "dgl_cvrp_step");
     return launch_cvrp_step<true, false>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                          tile_out, stream, "dgl_cvrp_step");
+}
+
+extern "C" int dgl_cvrp_step_beam(const dgl_cvrp_state_t *src, const dgl_cvrp_state_t *dst, const int32_t *prev_k,
+                                  int32_t beam, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                                  int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out,
+                                  float *tile_out, int32_t *hist_action, int32_t *hist_parent, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(src)) return e;
+    if (int e = check_cvrp_state(dst)) return e;
+    DGL_CHECK_ARG(action != nullptr && prev_k != nullptr && hist_action != nullptr && hist_parent != nullptr, "NULL argument");
+    DGL_CHECK_ARG(beam >= 1 && src->R == dst->R && src->N == dst->N && src->R % beam == 0 && src->xy == dst->xy &&
+                      src->demand == dst->demand && src->demand_in_distance == dst->demand_in_distance,
+                  "src/dst differ in shape or instance, or R %% beam != 0");
+    DGL_CHECK_ARG(src->avg != dst->avg && src->sd != dst->sd && src->visited != dst->visited && src->capacity != dst->capacity &&
+                      src->nodes != dst->nodes && src->flags != dst->flags, "src and dst must be different buffers");
+    DGL_CHECK_ARG(t >= 2 && t <= dst->N, "t=%d outside [2,N=%d] (the first step has no back-pointer)", t, dst->N);
+    const bool want = idx_last_out != nullptr;
+    DGL_CHECK_ARG(want == (idx_depot_out != nullptr) && want == (infeasible_out != nullptr) && want == (tile_out != nullptr),
+                  "idx_last_out, idx_depot_out, infeasible_out and tile_out must all be given or all be NULL");
+    DGL_CHECK_ARG(!want || (knn >= 1 && depot_knn >= 1), "knn=%d depot_knn=%d must be >= 1", knn, depot_knn);
+    if (!want) knn = depot_knn = 1;
+    const CvrpBeamLink link{src->avg, src->sd, src->capacity, src->visited, src->nodes, src->flags, prev_k, beam,
+                            hist_action, hist_parent};
+    if (dst->demand_in_distance)
+        return launch_cvrp_step<true, true>(dst, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                            tile_out, stream, "dgl_cvrp_step_beam", link);
+    return launch_cvrp_step<true, false>(dst, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                         tile_out, stream, "dgl_cvrp_step_beam", link);
+}
+
+// nodes / flags of steps t_last .. t_first from the history of linked steps: one thread walks one row's back-pointers
+__global__ void cvrp_backtrack_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ hist_action,
+                                      const int32_t *__restrict__ hist_parent, int t_first, int t_last) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= st.R) return;
+    const int N = st.N;
+    int p = r;
+    for (int t = t_last; t >= t_first; --t) {
+        const size_t e = (size_t)(t - 1) * st.R + p;
+        const int act = hist_action[e];
+        const bool via = act > N;                               // CVRP/CVRPEnv.py:612-622
+        st.nodes[(size_t)r * N + (t - 1)] = via ? act - (N + 1) : act;
+        st.flags[(size_t)r * N + (t - 1)] = via ? 1 : 0;
+        p = min(max(hist_parent[e], 0), st.R - 1);
+    }
+}
+
+extern "C" int dgl_cvrp_beam_backtrack(const dgl_cvrp_state_t *st, const int32_t *hist_action, const int32_t *hist_parent,
+                                       int32_t t_first, int32_t t_last, dgl_stream_t stream) {
+    if (int e = check_cvrp_state(st)) return e;
+    DGL_CHECK_ARG(hist_action != nullptr && hist_parent != nullptr, "NULL history");
+    DGL_CHECK_ARG(t_first >= 2 && t_last <= st->N && t_first <= t_last, "steps [%d,%d] outside [2,N=%d]", t_first, t_last, st->N);
+    hipLaunchKernelGGL(cvrp_backtrack_kernel, dim3((st->R + 63) / 64), dim3(64), 0, (hipStream_t)stream, *st, hist_action,
+                       hist_parent, t_first, t_last);
+    DGL_CHECK_LAUNCH("dgl_cvrp_beam_backtrack");
+    return DGL_OK;
 }
 
 extern "C" int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, int32_t depot_knn,

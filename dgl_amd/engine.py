@@ -464,8 +464,33 @@ class CvrpEngine:
                                                 2 * (self.N + 1), step, ptr(prev_k), ptr(action), stream_ptr()),
               "dgl_beam_advance_compact")
 
+    def step_beam(self, prev_k: torch.Tensor, action: torch.Tensor, beam: int) -> None:
+        """Back-pointer gather and step in one pass over the state (other buffer <- this buffer); nodes and flags
+        are rebuilt from the history by ``backtrack``."""
+        assert len(self.bufs) == 2 and prev_k.dtype == torch.int32 and action.dtype == torch.int32
+        if getattr(self, "hist_action", None) is None:
+            self.hist_action = torch.zeros(self.N, self.R, dtype=torch.int32, device=self.device)
+            self.hist_parent = torch.zeros(self.N, self.R, dtype=torch.int32, device=self.device)
+        src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
+        self.t += 1
+        more = self.t < self.N
+        check(self.lib.dgl_cvrp_step_beam(ctypes.byref(src["struct"]), ctypes.byref(dst["struct"]), ptr(prev_k), beam,
+                                          ptr(action), self.t, self.knn, self.depot_knn,
+                                          ptr(self.idx_last) if more else 0, ptr(self.idx_dep) if more else 0,
+                                          ptr(self.infeasible) if more else 0, ptr(self.tile) if more else 0,
+                                          ptr(self.hist_action), ptr(self.hist_parent), stream_ptr()), "dgl_cvrp_step_beam")
+        self.cur = 1 - self.cur
+        if more:
+            self.tile_t = self.t
+
+    def backtrack(self, t_first: int) -> None:
+        check(self.lib.dgl_cvrp_beam_backtrack(ctypes.byref(self.state["struct"]), ptr(self.hist_action),
+                                               ptr(self.hist_parent), t_first, self.t, stream_ptr()),
+              "dgl_cvrp_beam_backtrack")
+
     def beam_rollout(self, policy: PackedPolicy, start_action: torch.Tensor, beam: int) -> torch.Tensor:
-        """Beam-search decode (CVRP/CVRPTester.py:147-227) on the compact state."""
+        """Beam-search decode (CVRP/CVRPTester.py:147-227) on the compact state; the step follows the
+        back-pointers while it updates, nodes and flags are rebuilt from the history at the end."""
         assert self.rpi % beam == 0 and len(self.bufs) == 2
         G = self.R // beam
         dev = self.device
@@ -478,8 +503,9 @@ class CvrpEngine:
         while self.t < self.N:
             self.forward(policy, want_logits=False, want_selected=False)
             self.beam_advance(scores, beam, step, prev_k, action)
-            self.permute(prev_k, beam)
-            self.step(action.view(-1))
+            self.step_beam(prev_k.view(-1), action.view(-1), beam)
             step += 1
+        if self.N >= 2:
+            self.backtrack(2)
         self.beam_scores = scores
         return self.route_length()

@@ -152,6 +152,18 @@ DGL_API int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int
                   int32_t depot_knn, int32_t *idx_last_out, int32_t *idx_depot_out,
                   uint8_t *infeasible_out, float *tile_out, dgl_stream_t stream);
 
+/* Beam-search step without a separate state gather (CVRPEnv.perm_attr, CVRP/CVRPEnv.py:536-581, followed by
+ * CVRPEnv.step): as dgl_tsp_step_beam; capacity is read from the parent row as well.  hist_action holds the
+ * action ids (node, or node + N + 1 for a move via the depot), dgl_cvrp_beam_backtrack rebuilds dst->nodes and
+ * dst->flags for steps t_first..t_last (2 <= t_first); entry 0 (the first move, shared by a beam group) is
+ * kept by every linked step. */
+DGL_API int dgl_cvrp_step_beam(const dgl_cvrp_state_t *src, const dgl_cvrp_state_t *dst, const int32_t *prev_k,
+                               int32_t beam, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                               int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                               int32_t *hist_action, int32_t *hist_parent, dgl_stream_t stream);
+DGL_API int dgl_cvrp_beam_backtrack(const dgl_cvrp_state_t *st, const int32_t *hist_action, const int32_t *hist_parent,
+                                    int32_t t_first, int32_t t_last, dgl_stream_t stream);
+
 /* CVRPModel.get_knn_state/_norm_node + tile assembly alone (CVRP/CVRPModel.py:51-187,258-309) for
  * the state after t steps.  Like the reference's get_knn_state it nudges capacities below 1e-5 by
  * +1e-7 in place (CVRP/CVRPModel.py:164-166), so call it at most once per decode step. */
