@@ -18,6 +18,9 @@
 #define COMPACT_CAP 8192    // beam * tokens upper bound for the compact kernel
 
 typedef unsigned long long u64;
+#define BEAM_FAST 32        // beams up to this size are extracted by repeated wave-wide maxima instead of a sort
+
+extern "C" __device__ u64 __ockl_wfred_max_u64(u64);       // wave-wide maximum (device library), broadcast to all lanes
 
 __device__ __forceinline__ unsigned ord_f32(float f) {
     unsigned u = __float_as_uint(f);
@@ -168,7 +171,31 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
         ckeys[e] = k;
     }
     __syncthreads();
-    block_sort_desc(ckeys, P);
+    // The `beam` largest explicit keys in descending order.  Few beams over at most 512 candidates: one wave holds
+    // all keys in registers and extracts the maximum `beam` times (keys are unique); otherwise a block-wide sort.
+    __shared__ u64 top[BEAM_FAST];
+    const bool fast = beam <= BEAM_FAST && P <= 512;
+    if (fast) {
+        if (tid < 64) {
+            u64 k[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) k[q] = (tid + 64 * q < P) ? ckeys[tid + 64 * q] : 0;
+            for (int o = 0; o < beam; ++o) {
+                u64 m = k[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) m = k[q] > m ? k[q] : m;
+                m = __ockl_wfred_max_u64(m);
+                if (tid == 0) top[o] = m;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k[q] = (k[q] == m) ? 0 : k[q];
+            }
+        }
+        __syncthreads();
+    } else {
+        block_sort_desc(ckeys, P);
+    }
+    const u64 *sorted = fast ? top : ckeys;
+    const int n_sorted = fast ? beam : P;
 
     // implicit candidates: every action of beam b that is not one of its tokens has probability 1e-20
     // (value log(1e-20) + score_b, or -1e20 for b > 0 at step 1).  They only matter when fewer than
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
         u64 fk = next_floor_key();
         int ci = 0;
         for (int o = 0; o < beam; ++o) {
-            const u64 ck = ci < P ? ckeys[ci] : 0;
+            const u64 ck = ci < n_sorted ? sorted[ci] : 0;
             if (ck >= fk) { result[o] = ck; ++ci; }
             else { result[o] = fk; ++a_next; fk = next_floor_key(); }
         }
