@@ -229,21 +229,44 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     // LDS keys of all lanes, and (for the feature loads below) the avg/sd stores of all lanes
     // SPLIT: wave 0 builds the group of the current node, wave 1 the depot's group, side by side
     const bool do_last = !SPLIT || wave == 0, do_depot = !SPLIT || wave == 1;
+    const int kd = min(depot_knn, N - t);                      // CVRP/CVRPModel.py:58,88
+    const int kl = min(knn, kd);                               // :123
+    // Long rows: every wave compacts the candidates of both groups over the range it scanned, into lists that
+    // waves 0 and 1 then concatenate (short rows: those two compact alone and the others retire at once).
+    const bool share = SPLIT && M >= 2048 && kd <= 64;
+    const float *lists = nullptr;
+    const int *counts = nullptr;
+    float boundL = 0.0f, boundD = 0.0f;
     if (SPLIT) {
-        if (wave >= 2) return;
+        if (!share && wave >= 2) return;
+        // LDS behind the row's arrays: scratch of wave 0 [128] | lane minima [2][64 WAVES] | scratch of wave 1 [128]
+        //                              | candidate lists [2][WAVES][128] | counts [2][WAVES]
         const float *mins = scratch + 128;
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             minL = fminf(minL, mins[64 * w + lane]);
             minD = fminf(minD, mins[WAVES * 64 + 64 * w + lane]);
+        }
+        if (share) {
+            float *lw = scratch + 256 + 2 * WAVES * 64;
+            int *cw = reinterpret_cast<int *>(lw + 2 * WAVES * 128);
+            boundL = __uint_as_float(wave_candidate_bound(minL, kl));
+            boundD = __uint_as_float(wave_candidate_bound(minD, kd));
+            float *mine = lw + 128 * wave;
+            const int cl = wave_compact(keysL, j_begin, j_end, boundL, mine, reinterpret_cast<int *>(mine) + 64);
+            mine += 128 * WAVES;
+            const int cd = wave_compact(keysD, j_begin, j_end, boundD, mine, reinterpret_cast<int *>(mine) + 64);
+            if (lane == 0) { cw[wave] = cl; cw[WAVES + wave] = cd; }
+            __syncthreads();                                   // `share` is uniform over the workgroup
+            if (wave >= 2) return;
+            lists = lw + 128 * WAVES * wave;
+            counts = cw + WAVES * wave;
         }
         if (wave == 1) scratch += 128 + 2 * WAVES * 64;        // a search scratch of its own
     } else {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-    const int kd = min(depot_knn, N - t);                      // CVRP/CVRPModel.py:58,88
-    const int kl = min(knn, kd);                               // :123
     const bool low = cap < 0.00001f;
     int32_t *il = idx_last_out + (size_t)r * knn;
     int32_t *id = idx_dep_out + (size_t)r * depot_knn;
@@ -260,7 +283,8 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     int cj;
     int c = -1;
     if (do_last) {
-    c = wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
+    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysL, M, kl, boundL, scratch, &ckey, &cj)
+              : wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
     if (c >= 0) {
         // inputs of every candidate's row (and of the anchor, on lane 63 when it holds no candidate)
         // are requested before the ranking bisection
@@ -293,7 +317,8 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
     }
     if (do_depot) {
     // neighbourhood of the depot: column 3 holds distance_to_depot (CVRP/CVRPModel.py:180-183)
-    c = wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj);
+    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysD, M, kd, boundD, scratch, &ckey, &cj)
+              : wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj);
     if (c >= 0) {
         const bool anchor_early = (c < 64) && (lane == 63);
         const int jl = anchor_early ? 0 : cj;
@@ -425,7 +450,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    const size_t lds_split = (size_t)(per_wave + 512 + 128) * sizeof(float);
+    const size_t lds_split = (size_t)(per_wave + 512 + 128 + 2 * 4 * 128 + 8) * sizeof(float);
     if ((st->R < 2048 || st->R >= 8192) && st->N >= 512 && lds_split <= 150 * 1024) {
         // few rows: four waves share a row
         if (lds_split > 48 * 1024)

@@ -76,11 +76,9 @@ __device__ __forceinline__ int wave_count_le(float v, unsigned x) { return __pop
 // are compacted in index order, one per lane.  Returns their number c (lane < c holds key and
 // index j), or -1 when more than 64 keys lie under the bound or k > 64 (then use
 // wave_select_general).  scratch: 128 words.
-__device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, float lane_min, float *scratch,
-                                               float *key_out, int *j_out) {
-    const int lane = threadIdx.x & 63;
+// the bound of step 1 as a bit pattern (k <= 64)
+__device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k) {
     const unsigned FMAX = 0x7F7FFFFFu;
-    if (k > 64) return -1;
     unsigned hi = FMAX;                     // fewer than k finite lane minima: every finite key is a candidate
     if (wave_count_le(lane_min, FMAX) >= k) {
         unsigned lo = 0;
@@ -97,15 +95,20 @@ __device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, 
         }
         hi = min(hi + 4u, FMAX);
     }
-    const float bound = __uint_as_float(hi);
-    int *cand_j = reinterpret_cast<int *>(scratch) + 64;
+    return hi;
+}
+
+// keys[j] <= bound for j in [j_lo, j_hi) (j_lo a multiple of 64), compacted in index order: the first 64 go to
+// out_key / out_j; returns how many there are (possibly more than 64)
+__device__ __forceinline__ int wave_compact(const float *keys, int j_lo, int j_hi, float bound, float *out_key, int *out_j) {
+    const int lane = threadIdx.x & 63;
     int c = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
+    for (int j0 = j_lo; j0 < j_hi; j0 += 256) {
         float key[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {       // four LDS reads in flight
             const int j = j0 + 64 * q + lane;
-            key[q] = j < n ? keys[j] : INFINITY;
+            key[q] = j < j_hi ? keys[j] : INFINITY;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -113,16 +116,68 @@ __device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, 
             const unsigned long long m = __ballot(p);
             const int pos = c + lane_rank(m);
             if (p && pos < 64) {
-                scratch[pos] = key[q];
-                cand_j[pos] = j0 + 64 * q + lane;
+                out_key[pos] = key[q];
+                out_j[pos] = j0 + 64 * q + lane;
             }
             c += __popcll(m);
         }
     }
+    return c;
+}
+
+// More than 64 keys lay under the first bound (about one row in some thousand: ~40 keys lie under the 30th smallest
+// of 64 lane minima, with a long tail).  first_key: the first 64 of them, one per lane: k of the row's keys lie
+// under their k-th smallest too, so it bounds the row's k-th smallest from above, and all but a few of the surplus
+// keys lie above it.  One more pass over the row's keys with that bound.
+__device__ __forceinline__ int wave_candidates_again(const float *keys, int n, int k, float first_key, float bound,
+                                                     float *scratch, float *key_out, int *j_out) {
+    const int lane = threadIdx.x & 63;
+    bound = fminf(bound, __uint_as_float(wave_candidate_bound(first_key, k)));
+    int *cand_j = reinterpret_cast<int *>(scratch) + 64;
+    wave_lds_sync();                        // every lane has read its first_key (it may come from scratch)
+    const int c = wave_compact(keys, 0, n, bound, scratch, cand_j);
     if (c > 64) return -1;
     wave_lds_sync();
     *key_out = lane < c ? scratch[lane] : INFINITY;
     *j_out = lane < c ? cand_j[lane] : 0;
+    return c;
+}
+
+__device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, float lane_min, float *scratch,
+                                               float *key_out, int *j_out) {
+    const int lane = threadIdx.x & 63;
+    if (k > 64) return -1;
+    const float bound = __uint_as_float(wave_candidate_bound(lane_min, k));
+    int *cand_j = reinterpret_cast<int *>(scratch) + 64;
+    const int c = wave_compact(keys, 0, n, bound, scratch, cand_j);
+    wave_lds_sync();
+    if (c > 64) return wave_candidates_again(keys, n, k, scratch[lane], bound, scratch, key_out, j_out);
+    *key_out = lane < c ? scratch[lane] : INFINITY;
+    *j_out = lane < c ? cand_j[lane] : 0;
+    return c;
+}
+
+// The same with the compaction shared by the W waves that scanned a row: wave w has compacted its own node range
+// into list w (wave_compact; 128 words per list: 64 keys, 64 indices) and left its count in counts[w]; the ranges
+// ascend with w, so the lists concatenate in index order.  Called by one wave after the workgroup barrier.
+__device__ __forceinline__ int wave_candidates_from_lists(const float *lists, const int *counts, int W, const float *keys,
+                                                          int n, int k, float bound, float *scratch, float *key_out,
+                                                          int *j_out) {
+    const int lane = threadIdx.x & 63;
+    int c = 0;
+    float key = INFINITY;
+    int j = 0;
+    for (int w = 0; w < W; ++w) {
+        const int cw = counts[w];
+        if (lane >= c && lane < c + cw) {       // a list holds the first 64 of its wave's cw candidates
+            key = lists[w * 128 + (lane - c)];
+            j = reinterpret_cast<const int *>(lists)[w * 128 + 64 + (lane - c)];
+        }
+        c += cw;
+    }
+    if (c > 64) return wave_candidates_again(keys, n, k, key, bound, scratch, key_out, j_out);
+    *key_out = key;
+    *j_out = j;
     return c;
 }
 

@@ -180,23 +180,42 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     if (!want_knn) return;
 
     // LDS keys of all lanes, and (for the staging loads below) the avg/sd stores of all lanes
-    if (SPLIT) {
-        float *mins = scratch + 128;
-        mins[threadIdx.x] = lane_min;
-        __syncthreads();                                    // keys, minima and the avg/sd stores of every wave
-        if (wave != 0) return;
-        // the 64 classes {lane of any wave} partition the keys as the lanes of one wave do
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) lane_min = fminf(lane_min, mins[64 * w + lane]);
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
     const int k = min(knn, u);
     int32_t *idx_row = idx_out + (size_t)r * knn;
     float ckey;
     int cj;
-    const int c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+    int c;
+    if (SPLIT) {
+        // LDS behind the row's arrays: lane minima [64 WAVES] | candidate lists [WAVES][128] | counts [WAVES]
+        float *mins = scratch + 128;
+        float *lists = mins + 64 * WAVES;
+        int *counts = reinterpret_cast<int *>(lists + 128 * WAVES);
+        mins[threadIdx.x] = lane_min;
+        __syncthreads();                                    // keys, minima and the avg/sd stores of every wave
+        // the 64 classes {lane of any wave} partition the keys as the lanes of one wave do
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) lane_min = fminf(lane_min, mins[64 * w + lane]);
+        // Long rows: every wave derives the same bound and compacts the candidates of the range it scanned (on
+        // long rows the compaction is the longest part of the selection); short rows: wave 0 does it alone and the
+        // others retire at once, which is what keeps saturating batches moving.
+        const bool share = N >= 2048 && k <= 64;
+        if (!share) {
+            if (wave != 0) return;
+            c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+        } else {
+            const float bound = __uint_as_float(wave_candidate_bound(lane_min, k));
+            const int cw = wave_compact(keys, j_begin, j_end, bound, lists + 128 * wave,
+                                        reinterpret_cast<int *>(lists + 128 * wave) + 64);
+            if (lane == 0) counts[wave] = cw;
+            __syncthreads();                                // `share` is uniform over the workgroup
+            if (wave != 0) return;
+            c = wave_candidates_from_lists(lists, counts, WAVES, keys, N, k, bound, scratch, &ckey, &cj);
+        }
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+    }
     if (c >= 0) {
         // The inputs of every candidate's feature row (and of the anchor token = the current node, on
         // lane 63 when that lane holds no candidate) are requested before the ranking bisection.
@@ -302,7 +321,7 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
                            float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    const size_t lds_split = (size_t)(per_wave + 256) * sizeof(float);
+    const size_t lds_split = (size_t)(per_wave + 4 * (64 + 128) + 4) * sizeof(float);
     static const int force_split = getenv("DGL_STEP_SPLIT") ? atoi(getenv("DGL_STEP_SPLIT")) : -1;   // experiments
     // measured at N = 1000: sharing a row wins below 2048 rows (latency) and from 8192 rows on (6-10 %)
     const bool split = force_split >= 0 ? force_split != 0 : ((st->R < 2048 || st->R >= 8192) && st->N >= 512);

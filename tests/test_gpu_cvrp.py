@@ -118,14 +118,16 @@ def test_state_data_matches_golden(name, device):
             assert np.all((cap == gcap) | ((gcap < 1e-5) & (np.abs(cap - gcap - 1e-7) < 1e-9)))
 
 
-def test_recurrences_bit_exact_vs_c_oracle(device):
+@pytest.mark.parametrize("N,knn,kd,until", [(150, 15, 20, None), (700, 15, 20, 60), (2500, 15, 15, 40)])
+def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
     """Synthetic instance, random feasible actions: state arithmetic and both neighbourhoods must be
-    bit-identical to the plain-C oracle."""
+    bit-identical to the plain-C oracle.  700 nodes: four waves share a row; 2500: they also share the
+    compaction of the candidates."""
     from dgl_amd.engine import CvrpEngine
     from oracle import cref
     lib = cref.load()
     rng = np.random.default_rng(3)
-    B, N, knn, kd = 2, 150, 15, 20
+    B = 2
     M = N + 1
     xy = rng.random((B, M, 2), dtype=np.float32)
     dem = np.concatenate([np.zeros((B, 1), np.float32), (rng.integers(1, 200, (B, N)) / 500.0).astype(np.float32)], 1)
@@ -135,7 +137,7 @@ def test_recurrences_bit_exact_vs_c_oracle(device):
     cap = np.ones(B, np.float32)
     visited = np.zeros((B, M), np.uint8)
     order = np.stack([rng.permutation(N) + 1 for _ in range(B)])
-    for t in range(1, N):
+    for t in range(1, N if until is None else until + 1):
         acts = np.zeros(B, np.int32)
         for b in range(B):
             node = int(order[b, t - 1])

@@ -94,6 +94,19 @@ def test_clustered(device):
     _run_case(device, xy, order, 30, check_until=120)
 
 
+@pytest.mark.parametrize("N", [300, 1000, 2500])
+def test_more_than_64_candidates(device, N):
+    """A tight cluster whose nodes all sit in 29 of the 64 index classes (index mod 64): the 30th smallest class
+    minimum is then a far node, more than 64 keys lie under it, and the selection has to take its second pass.
+    One wave per row, four waves per row, and four waves that also share the compaction."""
+    rng = np.random.default_rng(N)
+    xy = (0.5 + 0.5 * rng.random((2, N, 2))).astype(np.float32)
+    near = np.array([j for j in range(N) if j % 64 < 29][:87])
+    xy[:, near] = (0.1 + 0.02 * rng.random((2, near.size, 2))).astype(np.float32)
+    order = np.stack([np.concatenate((rng.permutation(near), np.setdiff1d(np.arange(N), near))) for _ in range(2)])
+    _run_case(device, xy, order, 30, check_until=25)
+
+
 def test_large_n(device):
     rng = np.random.default_rng(5)
     N = 5000

@@ -5,7 +5,8 @@ from dgl_amd import _lib
 from dgl_amd._lib import check, ptr, stream_ptr
 from dgl_amd.engine import TspEngine
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-N, knn, iters = 1000, 30, 30
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+knn, iters = 30, 30
 dev = torch.device('cuda:0')
 eng = TspEngine(torch.rand(R, N, 2, device=dev), 1, knn)
 lib = _lib.load()
