@@ -61,6 +61,41 @@ __device__ __forceinline__ float dgl_sqrt(float x) {
     return s;
 }
 
+// Two-wide float arithmetic: gfx950 issues v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 for these, one instruction for
+// two independent correctly rounded results (the scan loops are bound by vector-ALU issue as much as by HBM).
+typedef float dgl_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dgl_f2 dgl_fma2(dgl_f2 a, dgl_f2 b, dgl_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ dgl_f2 dgl_splat2(float v) { return dgl_f2{v, v}; }
+
+// dgl_sqrt with both residuals in one packed FMA
+__device__ __forceinline__ float dgl_sqrt_pk(float x) {
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s0) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s0) + 1u);
+    const dgl_f2 res = dgl_fma2(-dgl_f2{s_dn, s_up}, dgl_splat2(s0), dgl_splat2(x));
+    float s = (res.x <= 0.0f) ? s_dn : s0;
+    s = (res.y > 0.0f) ? s_up : s;
+    return s;
+}
+
+// One node's running mean / standard deviation of its distances to the unvisited nodes when the node at distance
+// dcol leaves that set (TSP/TSPEnv.py:386,408-409; CVRP/CVRPEnv.py:711,733-738): up1 = u + 1, du = division by u,
+//   avg' = (avg up1 - dcol) / u,   sd' = sqrt((sd^2 up1 - (dcol - avg)^2) / u)   (CLAMP: radicand < 0 -> 0).
+// The same roundings as the scalar formulas, with the two numerators and the two divisions in packed instructions.
+template <bool CLAMP>
+__device__ __forceinline__ void dgl_update_moments(float dcol, float a0, float s0, float up1, const DglConstDiv &du,
+                                                   float *a1, float *s1) {
+    const float e = __fsub_rn(dcol, a0);
+    const dgl_f2 num = dgl_f2{a0, __fmul_rn(s0, s0)} * dgl_splat2(up1) - dgl_f2{dcol, __fmul_rn(e, e)};
+    const dgl_f2 q = num * dgl_splat2(du.rb);
+    const dgl_f2 rem = dgl_fma2(-q, dgl_splat2(du.b), num);
+    const dgl_f2 res = dgl_fma2(rem, dgl_splat2(du.rb), q);
+    float item = res.y;
+    if (CLAMP && item < 0.0f) item = 0.0f;
+    *a1 = res.x;
+    *s1 = dgl_sqrt_pk(item);
+}
+
 // |p|^2 as the reference's x.pow(2).sum(-1): two rounded products, one rounded add.
 __device__ __forceinline__ float dgl_sqnorm(float x, float y) { return __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)); }
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t 
                                                               float *__restrict__ tile_out, int lds_per_wave,
                                                               CvrpBeamLink link) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar registers
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
     if (r >= st.R) return;
     const int N = st.N, M = N + 1, W = (M + 63) / 64;

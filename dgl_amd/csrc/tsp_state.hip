@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
                                                              float *__restrict__ tile_out, int lds_per_wave,
                                                              TspBeamLink link) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar registers
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
     if (r >= st.R) return;                                  // uniform over the waves that meet at a barrier below
     const int N = st.N, W = (N + 63) / 64;
@@ -142,12 +142,9 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
                 const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
                 const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
-                    const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));          // dis[j][cur]
-                    // TSP/TSPEnv.py:386, 408-409
-                    const float a0 = g.a0[q], s0 = g.s0[q];
-                    const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);
-                    const float e = __fsub_rn(dcol, a0);
-                    const float s1 = dgl_sqrt(dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du));
+                    const float dcol = dgl_sqrt_pk(dgl_chain_sq(cross, nj, cx.nc));       // dis[j][cur]
+                    float a1, s1;
+                    dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1);   // TSP/TSPEnv.py:386, 408-409
                     avg[j] = a1;
                     sd[j] = s1;
                 }
