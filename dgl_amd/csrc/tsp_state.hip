@@ -69,7 +69,7 @@ struct TspBeamLink {
 template <int WAVES, bool UPDATE, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
-                                                             float *__restrict__ tile_out, int lds_per_wave,
+                                                             float *__restrict__ tile_out, int lds_per_wave, int mom_off,
                                                              TspBeamLink link) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar registers
@@ -79,6 +79,9 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     float *keys = lds + (SPLIT ? 0 : (size_t)wave * lds_per_wave);
     float *tile = keys + N;
     float *scratch = tile + (knn + 1) * DGL_TILE_STRIDE;
+    // mom_off != 0 (UPDATE only): the row's new (avg, sd) pairs are also kept in LDS, so that the feature rows of the
+    // candidates do not fetch them back from memory (at saturating batches half of those lines have left the L2)
+    float2 *mom = (UPDATE && mom_off) ? reinterpret_cast<float2 *>(keys + mom_off) : nullptr;
     // this wave's node range [j_begin, j_end): whole groups of STEP_UNROLL chunks
     int j_begin = 0, j_end = N;
     if (SPLIT) {
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
             if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
                 const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
+                float a1 = 0.0f, s1 = 0.0f;
                 if (UPDATE) {
                     const float dcol = dgl_sqrt_pk(dgl_chain_sq(cross, nj, cx.nc));       // dis[j][cur]
-                    float a1, s1;
                     dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1);   // TSP/TSPEnv.py:386, 408-409
                     avg[j] = a1;
                     sd[j] = s1;
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
                     const float key = dgl_inf_where(excl, dgl_chain_sq(cross, cx.nc, nj));
                     keys[j] = key;
                     lane_min = fminf(lane_min, key);
+                    if (UPDATE && mom) mom[j] = make_float2(a1, s1);
                 }
             }
         }
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         const bool anchor_early = (c < 64) && (lane == 63);
         const int jl = anchor_early ? cur : cj;
         const float2 p = xy2[jl];
-        const float av = avg[jl], sv = sd[jl];
+        float av, sv;
+        if (mom) { const float2 m = mom[jl]; av = m.x; sv = m.y; } else { av = avg[jl]; sv = sd[jl]; }
         int rank;
         const bool pick = wave_pick_k(dgl_sqrt(ckey), c, k, &rank);
         if (pick) idx_row[rank] = cj;
@@ -318,7 +323,12 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
                            float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    const size_t lds_split = (size_t)(per_wave + 4 * (64 + 128) + 4) * sizeof(float);
+    // shared-row shape, rows of up to 2048 nodes: 8 N more bytes of LDS hold the new (avg, sd) pairs
+    static const int force_mom = getenv("DGL_STEP_MOM") ? atoi(getenv("DGL_STEP_MOM")) : -1;                // experiments
+    const bool with_mom = UPDATE && (force_mom >= 0 ? force_mom != 0 : st->N <= 2048);
+    const int split_floats = per_wave + 4 * (64 + 128) + 4;
+    const int mom_off = with_mom ? (split_floats + 1) & ~1 : 0;
+    const size_t lds_split = (size_t)(with_mom ? mom_off + 2 * st->N : split_floats) * sizeof(float);
     static const int force_split = getenv("DGL_STEP_SPLIT") ? atoi(getenv("DGL_STEP_SPLIT")) : -1;   // experiments
     // measured at N = 1000: sharing a row wins below 2048 rows (latency) and from 8192 rows on (6-10 %)
     const bool split = force_split >= 0 ? force_split != 0 : ((st->R < 2048 || st->R >= 8192) && st->N >= 512);
@@ -328,10 +338,10 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave, link);
+                           *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave, link);
+                           *st, selected, t, knn, idx_out, tile_out, per_wave, 0, link);
     } else {
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
@@ -339,7 +349,7 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1, UPDATE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         hipLaunchKernelGGL((tsp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
-                           selected, t, knn, idx_out, tile_out, per_wave, link);
+                           selected, t, knn, idx_out, tile_out, per_wave, 0, link);
     }
     DGL_CHECK_LAUNCH(what);
     return DGL_OK;
