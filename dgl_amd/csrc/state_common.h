@@ -5,7 +5,7 @@
 // Row mean / population std of the pairwise distance matrix of one instance, without
 // storing the matrix (TSP/TSPEnv.py:228-235, CVRP/CVRPEnv.py:475-482).
 // grid: (ceil(M / 256), B), block 256; thread t handles node i = 256*blockIdx.x + t and sums
-// d(i, j) over j = 0..M-1 in binary64 (rounded once at the end).  The instance's coordinates are
+// d(i, j) over j = 0..M-1 in binary64 (four interleaved partial sums, rounded once at the end).  The instance's coordinates are
 // staged once per block in LDS (dynamic, 8*M bytes) and read back as broadcasts (every lane reads
 // the same j).  Also clears the visited bitmask.  z (may be NULL): a third coordinate per node
 // ([B][M]; the CVRP training reset measures distances over (x, y, demand), CVRP/CVRPEnv.py:519):
@@ -29,24 +29,51 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, con
         double s = 0.0, q = 0.0;
         if (z == nullptr) {
             const float ni = dgl_sqnorm(xi, yi);
-#pragma unroll 4
-            for (int j = 0; j < M; ++j) {
+            // four independent accumulator pairs: the binary64 adds of one pair would otherwise form one dependent chain
+            double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+            int j = 0;
+            for (; j + 4 <= M; j += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 pj = pts[j + e];
+                    const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
+                    s4[e] += d;
+                    q4[e] = fma(d, d, q4[e]);
+                }
+            }
+            for (; j < M; ++j) {
                 const float2 pj = pts[j];
                 const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
-                s += d;
-                q = fma(d, d, q);
+                s4[0] += d;
+                q4[0] = fma(d, d, q4[0]);
             }
+            s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
         } else {
             const float zi = lds_z[i], ni = __fadd_rn(dgl_sqnorm(xi, yi), __fmul_rn(zi, zi));
-#pragma unroll 4
-            for (int j = 0; j < M; ++j) {
+            auto dist3 = [&](int j) {
                 const float2 pj = pts[j];
                 const float zj = lds_z[j], nj = __fadd_rn(dgl_sqnorm(pj.x, pj.y), __fmul_rn(zj, zj));
                 const float cross = __fmaf_rn(-2.0f * zi, zj, dgl_chain_cross(xi, yi, pj.x, pj.y));
-                const double d = (double)dgl_sqrt(dgl_chain_sq(cross, ni, nj));
-                s += d;
-                q = fma(d, d, q);
+                return (double)dgl_sqrt(dgl_chain_sq(cross, ni, nj));
+            };
+            double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+            int j = 0;
+            for (; j + 4 <= M; j += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = dist3(j + e);
+                    s4[e] += d;
+                    q4[e] = fma(d, d, q4[e]);
+                }
             }
+            for (; j < M; ++j) {
+                const double d = dist3(j);
+                s4[0] += d;
+                q4[0] = fma(d, d, q4[0]);
+            }
+            s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
         }
         const double mean = s / M;
         const double var = q / M - mean * mean;
