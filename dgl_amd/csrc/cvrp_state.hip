@@ -83,7 +83,7 @@ struct CvrpBeamLink {
 };
 
 template <int WAVES, bool UPDATE, bool D3, bool SPLIT = false>
-__global__ __launch_bounds__(WAVES * 64) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
                                                               int32_t *__restrict__ idx_dep_out,
