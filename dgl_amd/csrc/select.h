@@ -74,8 +74,11 @@ __device__ __forceinline__ int wave_count_le(float v, unsigned x) { return __pop
 // minima under B about -64 ln(1 - m/64) keys are: 40 for m = 30); every radicand whose root can
 // tie with that of a key <= B lies within 2 ulps above B, so B is raised by 4 ulps; the keys <= B
 // are compacted in index order, one per lane.  Returns their number c (lane < c holds key and
-// index j), or -1 when more than 64 keys lie under the bound or k > 64 (then use
-// wave_select_general).  scratch: 128 words.
+// index j).  More than 64 keys under the bound: one more pass with the tighter bound that the first 64
+// candidates give (wave_candidates_again).  -1 when that fails too or k > 64 (then use
+// wave_select_general).  scratch: 128 words.  The pieces (the bound, the compaction of a node range, the
+// concatenation of per-wave lists) are separate so that the waves sharing a row can split the work.
+//
 // the bound of step 1 as a bit pattern (k <= 64)
 __device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k) {
     const unsigned FMAX = 0x7F7FFFFFu;
