@@ -28,5 +28,6 @@ def run(full, base):
     return a.elapsed_time(b) / iters
 for full in (False, True, False, True):
     ms = run(full, 0 if not full else iters + 3)
+    # per-row figure with a demand read per node (the kernel itself reads the demand of the candidates only: 24 N)
     by = (28 * N + N / 8 + (8 * (knn + kd) if full else 0)) * R
     print(f"R={R} N={N} {'whole step' if full else 'state update only'}: {ms*1e3:.1f} us, {by/ms/1e6:.0f} GB/s")
