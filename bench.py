@@ -45,7 +45,8 @@ def policy_flops_per_row(n: int, feat: int, anchors: int) -> float:
 
 
 def knn_bytes_per_row(nodes: int, k: int, cvrp: bool) -> float:
-    """Algorithmic HBM bytes of the fused state-update + kNN + tile kernel per row and step."""
+    """Algorithmic HBM bytes of the fused state-update + kNN + tile kernel per row and step.  The CVRP figure counts
+    one demand read per node; the kernel reads the demand of the candidates only (about 24 m bytes really move)."""
     if cvrp:
         m = nodes + 1
         return 28 * m + m / 4 + 8 * k
@@ -220,6 +221,9 @@ def main():
                              "traffic": pmc_traffic(args, B, knn, "step_kernel"),
                              "avg_launch_ms": ms_knn, "event_interval_ms": raw_knn, "bytes_per_launch": bytes_knn, "rows": B},
         }
+        if cvrp:
+            out["roofline_knn"]["bytes_note"] = ("per-row figure 28 m + m/4 + 8 (k + kd) with a demand read per node; the "
+                                                 "kernel reads the candidates' demand only, about 24 m bytes move")
         if not args.no_aux and world == 1:
             out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, args.problem, N, knn)
             if split:                                # the f32-input kernel on tiles of the same shape, outside the timed region
