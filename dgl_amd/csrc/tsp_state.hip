@@ -52,7 +52,8 @@ __device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const Ts
 // SPLIT: the WAVES waves of a workgroup share ONE row: each scans a contiguous quarter of the nodes
 // (state update + keys into the shared LDS array), then wave 0 alone selects and writes the tile.
 // With few rows this is what hides the memory latency of the scan (one wave per row leaves most
-// SIMDs with a single wave and every load exposed).  LDS: the row's arrays + 64 * WAVES lane minima.
+// SIMDs with a single wave and every load exposed).  LDS: the row's arrays + 64 * WAVES lane minima + per-wave
+// candidate lists (long rows: the waves share the compaction too) + optionally the row's new (avg, sd) pairs.
 // Beam search: row r of the state being written continues row (r / beam) * beam + prev_k[r] of another copy of the
 // state (its back-pointer).  The step then reads avg / sd / visited of that row and writes row r, which replaces
 // the separate gather of the whole state; the chosen node and the parent row go to a history from which the tours
