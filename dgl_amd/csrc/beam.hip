@@ -20,7 +20,15 @@
 typedef unsigned long long u64;
 #define BEAM_FAST 32        // beams up to this size are extracted by repeated wave-wide maxima instead of a sort
 
-extern "C" __device__ u64 __ockl_wfred_max_u64(u64);       // wave-wide maximum (device library), broadcast to all lanes
+extern "C" __device__ unsigned __ockl_wfred_max_u32(unsigned);   // wave-wide maximum (device library), broadcast to all lanes
+// the same for a 64-bit key as two 32-bit reductions (one DPP max per step each): high words, then the low words
+// of the lanes that hold the largest high word
+__device__ __forceinline__ u64 wave_max_key(u64 k) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned mh = __ockl_wfred_max_u32(hi);
+    const unsigned ml = __ockl_wfred_max_u32(hi == mh ? lo : 0u);
+    return ((u64)mh << 32) | ml;
+}
 
 __device__ __forceinline__ unsigned ord_f32(float f) {
     unsigned u = __float_as_uint(f);
@@ -161,9 +169,11 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
         u64 k = 0;
         if (e < ncand) {
             const int b = e / n, tok = e % n, r = g * beam + b;
+            // (requested before the action is known: two independent loads instead of two round trips)
+            const float pv = prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok];
             const int act = token_action(io, r, tok);
             if (act >= 0) {
-                const float lpv = logf(prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok]);
+                const float lpv = logf(pv);
                 const float v = step >= 2 ? __fadd_rn(lpv, sc[b]) : (b == 0 ? lpv : -1e20f);
                 k = make_key(v, (unsigned)b * (unsigned)A + (unsigned)act);
             }
@@ -180,14 +190,23 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
             u64 k[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) k[q] = (tid + 64 * q < P) ? ckeys[tid + 64 * q] : 0;
+            // each lane sorts its eight keys once (descending, 19 compare-exchanges); its largest is then k[0], and
+            // the lane that owned an extracted maximum shifts its list up
+#define BEAM_CE(i, j) { const u64 a_ = k[i], b_ = k[j]; const bool sw_ = a_ < b_; k[i] = sw_ ? b_ : a_; k[j] = sw_ ? a_ : b_; }
+            BEAM_CE(0, 1) BEAM_CE(2, 3) BEAM_CE(4, 5) BEAM_CE(6, 7)
+            BEAM_CE(0, 2) BEAM_CE(1, 3) BEAM_CE(4, 6) BEAM_CE(5, 7)
+            BEAM_CE(1, 2) BEAM_CE(5, 6)
+            BEAM_CE(0, 4) BEAM_CE(1, 5) BEAM_CE(2, 6) BEAM_CE(3, 7)
+            BEAM_CE(2, 4) BEAM_CE(3, 5)
+            BEAM_CE(1, 2) BEAM_CE(3, 4) BEAM_CE(5, 6)
+#undef BEAM_CE
             for (int o = 0; o < beam; ++o) {
-                u64 m = k[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) m = k[q] > m ? k[q] : m;
-                m = __ockl_wfred_max_u64(m);
+                const u64 m = wave_max_key(k[0]);
                 if (tid == 0) top[o] = m;
+                const bool mine = k[0] == m;            // keys are unique (0 = none left: shifting zeros is harmless)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) k[q] = (k[q] == m) ? 0 : k[q];
+                for (int q = 0; q < 7; ++q) k[q] = mine ? k[q + 1] : k[q];
+                k[7] = mine ? 0 : k[7];
             }
         }
         __syncthreads();
@@ -200,16 +219,21 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
     // implicit candidates: every action of beam b that is not one of its tokens has probability 1e-20
     // (value log(1e-20) + score_b, or -1e20 for b > 0 at step 1).  They only matter when fewer than
     // `beam` explicit candidates beat the best of them; one thread then merges the two sorted streams.
+    // best implicit group: highest value, then lowest beam index (every thread computes the same pair)
+    const float lfloor = logf(1e-20f);
+    int bstar = 0;
+    float fbest = -INFINITY;
+    for (int b = 0; b < beam; ++b) {
+        const float v = step >= 2 ? __fadd_rn(lfloor, sc[b]) : (b == 0 ? lfloor : -1e20f);
+        if (v > fbest) { fbest = v; bstar = b; }
+    }
+    // the usual case: the beam-th explicit candidate has a higher value than any implicit one
+    if (n_sorted >= beam && (unsigned)(sorted[beam - 1] >> 32) > ord_f32(fbest)) {
+        write_result(sorted, beam, A, scores + (size_t)g * beam, prev_k_out + (size_t)g * beam, action_out + (size_t)g * beam);
+        return;
+    }
     u64 *result = ckeys + P;
     if (tid == 0) {
-        const float lfloor = logf(1e-20f);
-        // best implicit group: highest value, then lowest beam index
-        int bstar = 0;
-        float fbest = -INFINITY;
-        for (int b = 0; b < beam; ++b) {
-            const float v = step >= 2 ? __fadd_rn(lfloor, sc[b]) : (b == 0 ? lfloor : -1e20f);
-            if (v > fbest) { fbest = v; bstar = b; }
-        }
         const int rstar = g * beam + bstar;
         int a_next = 0, tok_scan = 0;        // walk beam bstar's actions in ascending order, skipping its tokens
         auto next_floor_key = [&]() -> u64 {
