@@ -67,7 +67,10 @@ struct TspBeamLink {
     int32_t *hist_node, *hist_parent;      // [N][R], entry (t - 1) * R + r
 };
 
-template <int WAVES, bool UPDATE, bool SPLIT = false>
+// STREAM: the state arrays are read and written with non-temporal hints.  With tens of thousands of rows the rows in
+// flight exceed the L2; streaming the arrays that are read once and written once past it keeps the coordinates resident
+// for the candidates' feature rows (16 384 rows of 1000 nodes: 10 % less fetch traffic, 4 % faster; slower below that).
+template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
                                                              float *__restrict__ tile_out, int lds_per_wave, int mom_off,
@@ -121,7 +124,10 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = min(j0 + 64 * q + lane, N - 1);
             g.p[q] = xy2[j];
-            if (UPDATE) { g.a0[q] = avg_in[j]; g.s0[q] = sd_in[j]; }
+            if (UPDATE) {
+                g.a0[q] = STREAM ? __builtin_nontemporal_load(avg_in + j) : avg_in[j];
+                g.s0[q] = STREAM ? __builtin_nontemporal_load(sd_in + j) : sd_in[j];
+            }
         }
     };
     Group nxt;
@@ -149,8 +155,13 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
                 if (UPDATE) {
                     const float dcol = dgl_sqrt_pk(dgl_chain_sq(cross, nj, cx.nc));       // dis[j][cur]
                     dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1);   // TSP/TSPEnv.py:386, 408-409
-                    avg[j] = a1;
-                    sd[j] = s1;
+                    if (STREAM) {
+                        __builtin_nontemporal_store(a1, avg + j);
+                        __builtin_nontemporal_store(s1, sd + j);
+                    } else {
+                        avg[j] = a1;
+                        sd[j] = s1;
+                    }
                 }
                 if (want_knn) {
                     const int chunk = (j0 >> 6) + q;
@@ -338,8 +349,12 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
         if (lds_split > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
-        hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+        if (with_mom && st->R >= 16384 && lds_split <= 48 * 1024)
+            hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true, true>), dim3(st->R), dim3(256), lds_split,
+                               (hipStream_t)stream, *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+        else
+            hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, selected, t, knn, idx_out, tile_out, per_wave, 0, link);

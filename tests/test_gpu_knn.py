@@ -64,10 +64,12 @@ def test_uniform_rows_shared_by_four_waves(device, N, knn, until):
     _run_case(device, xy, order, knn, check_until=until)
 
 
-def test_many_rows_shared_by_four_waves(device):
-    """The saturating-batch variant of the same kernel (8192 rows and more)."""
+@pytest.mark.parametrize("B", [8192, 16384])
+def test_many_rows_shared_by_four_waves(device, B):
+    """The saturating-batch variant of the same kernel (8192 rows and more; from 16384 rows on the state arrays are
+    streamed past the L2 with non-temporal loads and stores)."""
     rng = np.random.default_rng(99)
-    B, N = 8192, 512
+    N = 512
     xy = rng.random((B, N, 2), dtype=np.float32)
     order = np.stack([rng.permutation(N)[:4] for _ in range(B)])
     order = np.concatenate((order, np.zeros((B, N - 4), dtype=order.dtype)), axis=1)
