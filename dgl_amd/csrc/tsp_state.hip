@@ -69,7 +69,8 @@ struct TspBeamLink {
 
 // STREAM: the state arrays are read and written with non-temporal hints.  With tens of thousands of rows the rows in
 // flight exceed the L2; streaming the arrays that are read once and written once past it keeps the coordinates resident
-// for the candidates' feature rows (16 384 rows of 1000 nodes: 10 % less fetch traffic, 4 % faster; slower below that).
+// for the candidates' feature rows.  Measured: it pays from about 16 million row-nodes on (16 384 x 1000: 10 % less fetch
+// traffic, 4 % faster; 24 576 x 1000 and 16 384 x 2000: 10-11 % faster) and costs 7-25 % with fewer (the launcher's rule).
 template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
@@ -349,7 +350,8 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
         if (lds_split > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
-        if (with_mom && st->R >= 16384 && lds_split <= 48 * 1024)
+        static const int force_stream = getenv("DGL_STEP_STREAM") ? atoi(getenv("DGL_STEP_STREAM")) : -1;          // experiments
+        if (with_mom && lds_split <= 48 * 1024 && (force_stream >= 0 ? force_stream != 0 : (long long)st->R * st->N >= 16000000ll))
             hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true, true>), dim3(st->R), dim3(256), lds_split,
                                (hipStream_t)stream, *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
         else

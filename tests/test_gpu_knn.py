@@ -8,22 +8,24 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(device, xy, visit_order, knn, check_until=None):
+def _run_case(device, xy, visit_order, knn, check_until=None, rows=None):
     """xy [B,N,2] float32 numpy; visit_order [B,N] permutation; drives the kernel with that order and
-    checks idx/avg/sd against the C oracle after every step."""
+    checks idx/avg/sd against the C oracle after every step (rows: only these rows are compared)."""
     from dgl_amd.engine import TspEngine
     from oracle import cref
     lib = cref.load()
     B, N = xy.shape[0], xy.shape[1]
+    rows = range(B) if rows is None else rows
+    sel = np.asarray(list(rows))
     eng = TspEngine(torch.from_numpy(xy).to(device), 1, knn)
     eng.reset()
     avg = eng.state["avg"].cpu().numpy().copy()
     sd = eng.state["sd"].cpu().numpy().copy()
     ref_avg, ref_sd = np.empty_like(avg), np.empty_like(sd)
-    for b in range(B):
+    for b in rows:
         lib.dglref_row_mean_std(np.ascontiguousarray(xy[b]), N, ref_avg[b], ref_sd[b])
-    np.testing.assert_allclose(avg, ref_avg, rtol=3e-7)
-    np.testing.assert_allclose(sd, ref_sd, rtol=3e-7)
+    np.testing.assert_allclose(avg[sel], ref_avg[sel], rtol=3e-7)
+    np.testing.assert_allclose(sd[sel], ref_sd[sel], rtol=3e-7)
     order = torch.from_numpy(visit_order.astype(np.int32)).to(device)
     visited = np.zeros((B, N), np.uint8)
     steps = N - 1 if check_until is None else check_until
@@ -31,7 +33,7 @@ def _run_case(device, xy, visit_order, knn, check_until=None):
         eng.step(order[:, t - 1].contiguous())
         idx = eng.idx.cpu().numpy()
         gavg, gsd = eng.state["avg"].cpu().numpy(), eng.state["sd"].cpu().numpy()
-        for b in range(B):
+        for b in rows:
             cur = int(visit_order[b, t - 1])
             visited[b, cur] = 1
             d = np.empty(N, np.float32)
@@ -41,8 +43,8 @@ def _run_case(device, xy, visit_order, knn, check_until=None):
             k = lib.dglref_tsp_knn(np.ascontiguousarray(xy[b]), N, cur, visited[b], knn, ref_idx)
             assert k == min(knn, N - t)
             assert (idx[b] == ref_idx).all(), (t, b, idx[b], ref_idx)
-        assert np.array_equal(gavg, avg, equal_nan=True), t
-        assert np.array_equal(gsd, sd, equal_nan=True), t
+        assert np.array_equal(gavg[sel], avg[sel], equal_nan=True), t
+        assert np.array_equal(gsd[sel], sd[sel], equal_nan=True), t
         avg, sd = gavg.copy(), gsd.copy()
 
 
@@ -66,14 +68,14 @@ def test_uniform_rows_shared_by_four_waves(device, N, knn, until):
 
 @pytest.mark.parametrize("B", [8192, 16384])
 def test_many_rows_shared_by_four_waves(device, B):
-    """The saturating-batch variant of the same kernel (8192 rows and more; from 16384 rows on the state arrays are
-    streamed past the L2 with non-temporal loads and stores)."""
+    """The saturating-batch variant of the same kernel (8192 rows and more; from 16 million row-nodes on the state
+    arrays are streamed past the L2 with non-temporal loads and stores: 16384 rows of 1000 nodes)."""
     rng = np.random.default_rng(99)
-    N = 512
+    N = 512 if B == 8192 else 1000
     xy = rng.random((B, N, 2), dtype=np.float32)
     order = np.stack([rng.permutation(N)[:4] for _ in range(B)])
     order = np.concatenate((order, np.zeros((B, N - 4), dtype=order.dtype)), axis=1)
-    _run_case(device, xy, order, 30, check_until=2)
+    _run_case(device, xy, order, 30, check_until=2, rows=None if B == 8192 else range(0, B, 16))
 
 
 def test_duplicate_points_tie_break(device):
