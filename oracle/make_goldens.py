@@ -314,6 +314,9 @@ TRAINED_CASES = {
     "tsp_n200_b2_beam8_nn": ("tsp", dict(seed=123, B=2, N=200, knn=30, beam=8)),
     "tsp_n100_b512_nn_tours": ("tsp", dict(seed=4242, B=512, N=100, knn=30, light="tours")),
     "cvrp_n100_b256_nn_tours": ("cvrp", dict(seed=4242, B=256, N=100, knn=15, depot_knn=15, light="tours")),
+    # the headline size: populations large enough for a ">= 99 % identical tours" assertion
+    "tsp_n1000_b128_nn_tours": ("tsp", dict(seed=2025, B=128, N=1000, knn=30, light="tours")),
+    "cvrp_n1000_b128_nn_tours": ("cvrp", dict(seed=2025, B=128, N=1000, knn=15, depot_knn=15, light="tours")),
     "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
     "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
     "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),
