@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DGL_AMD_LIB", os.path.join(_HERE, "lib", "libdgl_amd.
 
 TILE_STRIDE = 12
 MAX_TOKENS = 32
+STATIC_WORKSPACE_FLOATS = 16 * 1024 * 1024   # DGL_STATIC_WORKSPACE_FLOATS
 PROBLEM_TSP = 0
 PROBLEM_CVRP = 1
 ARITH_SPLIT_F16 = 0    # f16 split-operand matrix cores, f32 accumulate (default)
@@ -81,6 +82,8 @@ SIGNATURES = {
     "dgl_policy_general_workspace_floats": (c_int64, [c_int32, c_int32]),
     "dgl_policy_general": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p]),
+    "dgl_policy_general_static": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
+                                            c_float, c_void_p, c_void_p]),
     "dgl_augment": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dgl_tsp_nearest_neighbour": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "dgl_cvrp_nearest_neighbour": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

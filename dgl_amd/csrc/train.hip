@@ -11,6 +11,8 @@
 // (v_mfma_f32_32x32x2_f32 = FMA chains); weight gradients are accumulated with float atomics.
 #include "policy_layout.h"
 
+#include <mutex>
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define HEADS 8
 #define HDIM 16
@@ -651,4 +653,53 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)grad->emb_b);
     DGL_CHECK_LAUNCH("dgl_policy_general (backward)");
     return DGL_OK;
+}
+
+// ------------------------------------------------------------ allocation-free variant
+// dgl_policy_general for callers that cannot allocate device memory (HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the workspace is a file-scope device array instead of an
+// argument.  Every device the library runs on holds its own copy of the array at its own address
+// until the process ends; the host learns that address once per device (hipGetSymbolAddress with the
+// device current) and hands it to the kernels exactly as dgl_policy_general hands them `ws`.  The
+// array's name itself is never passed to a kernel or a copy from host code.
+// All calls on one device share the array: calls that overlap in time on one device race.  Nothing
+// in the workspace has to start at zero (every buffer is written in full before it is read), so the
+// previous call's contents are simply overwritten.
+static __device__ __align__(256) float scratch[DGL_STATIC_WORKSPACE_FLOATS];
+
+#define DGL_MAX_DEVICES 64
+static float *scratch_ptr[DGL_MAX_DEVICES];          // per device, filled on the first call on that device
+static std::mutex scratch_mutex;
+
+static int static_workspace(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return dgl_set_error(DGL_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= DGL_MAX_DEVICES) return dgl_set_error(DGL_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, DGL_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr)
+            return dgl_set_error(DGL_ERR_LAUNCH, "hipGetSymbolAddress(static workspace) on device %d: %s", dev,
+                                 hipGetErrorString(e));
+        scratch_ptr[dev] = static_cast<float *>(p);
+    }
+    *out = scratch_ptr[dev];
+    return DGL_OK;
+}
+
+extern "C" int dgl_policy_general_static(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
+                                         const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,
+                                         float *teacher_prob_out, dgl_stream_t stream) {
+    DGL_CHECK_ARG(io != nullptr, "NULL argument");
+    DGL_CHECK_ARG(io->R > 0 && io->n >= 2 && io->n <= 256, "R=%d, n=%d (2 <= n <= 256)", io->R, io->n);
+    const size_t need = ws_floats(io->R, io->n);
+    DGL_CHECK_ARG(need <= (size_t)DGL_STATIC_WORKSPACE_FLOATS,
+                  "R=%d rows of n=%d tokens need %zu floats of workspace, the static workspace holds %zu "
+                  "(use dgl_policy_general with a caller-owned workspace)",
+                  io->R, io->n, need, (size_t)DGL_STATIC_WORKSPACE_FLOATS);
+    float *ws = nullptr;
+    if (int e = static_workspace(&ws)) return e;
+    return dgl_policy_general(w, grad, io, teacher, grad_scale, ws, teacher_prob_out, stream);
 }

@@ -282,6 +282,20 @@ DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_w
                                const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,
                                float *ws, float *teacher_prob_out, dgl_stream_t stream);
 
+/* dgl_policy_general without a workspace argument, for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  The workspace is a device array inside the library of DGL_STATIC_WORKSPACE_FLOATS floats (64 MiB,
+ * held on every device the library runs on until the process ends), so
+ * dgl_policy_general_workspace_floats(io->R, io->n) must not exceed that (about 2500 tokens: 12 rows of 202
+ * tokens, 79 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
+ * No hipMalloc / hipFree or other allocating call is made.  The first call on a device looks the array's
+ * address up (make it outside graph capture).  All calls on one device share the array: calls that overlap in
+ * time on one device race.  Arguments and results otherwise exactly as dgl_policy_general. */
+#define DGL_STATIC_WORKSPACE_FLOATS (16 * 1024 * 1024)
+DGL_API int dgl_policy_general_static(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
+                                      const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,
+                                      float *teacher_prob_out, dgl_stream_t stream);
+
 /* optimizer.step() of torch.optim.Adam(lr, betas, eps, weight_decay) as the reference configures
  * it (CVRP/train.py:49-54, CVRP/CVRPTrainer.py:272) over a flat parameter vector of n floats;
  * step = 1, 2, ... ; grads are multiplied by grad_scale first (1/world_size after a sum

@@ -37,7 +37,8 @@ def test_ctypes_binding_covers_header():
 def test_every_entry_point_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "dgl_amd.h")).read()
     for name in _declared():
-        if name in ("dgl_version", "dgl_last_error_string", "dgl_policy_packed_floats", "dgl_policy_pack"):
+        if name in ("dgl_version", "dgl_last_error_string", "dgl_policy_packed_floats", "dgl_policy_pack",
+                    "dgl_policy_general_static"):      # no counterpart in the reference (says so in its comment)
             continue
         pos = text.index(name + "(")
         comment = text[text.rfind("/*", 0, pos):pos]
