@@ -113,7 +113,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
     cx.rowM = (size_t)r * M;
 
     // ---- action decoding, capacity (CVRP/CVRPEnv.py:612-631)
-    const int act = UPDATE ? __builtin_amdgcn_readfirstlane(action[r]) : 0;     // wave-uniform: scalar registers
+    // wave-uniform: scalar registers (clamped: an action id outside [0, 2(N+1)) must not turn into a wild address)
+    const int act = UPDATE ? min(max(__builtin_amdgcn_readfirstlane(action[r]), 0), 2 * N + 1) : 0;
     const bool via = act > N;
     const int cur = UPDATE ? (via ? act - (N + 1) : act) : __builtin_amdgcn_readfirstlane(st.nodes[(size_t)r * N + (t - 1)]);
     const float dem_cur = cx.demb[cur];
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void cvrp_length_kernel(dgl_cvrp_state_t st, f
 // ------------------------------------------------------------------ beam permutation
 __global__ __launch_bounds__(256) void cvrp_permute_kernel(dgl_cvrp_state_t src, dgl_cvrp_state_t dst,
                                                           const int32_t *__restrict__ prev_k, int beam, int t) {
-    const int r = blockIdx.x, g = r / beam, sr = g * beam + prev_k[r];
+    const int r = blockIdx.x, g = r / beam, sr = g * beam + min(max(prev_k[r], 0), beam - 1);
     const int N = src.N, M = N + 1, W = (M + 63) / 64;
     const size_t so = (size_t)sr * M, d0 = (size_t)r * M;
     for (int j = threadIdx.x; j < M; j += blockDim.x) {
@@ -428,6 +429,10 @@ static int check_cvrp_state(const dgl_cvrp_state_t *st) {
     DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
     DGL_CHECK_ARG(st->xy && st->demand && st->avg && st->sd && st->capacity && st->visited && st->nodes && st->flags,
                   "NULL state buffer");
+    // (see check_tsp_state: torch.cdist's direct path for at most 25 points)
+    if (st->N + 1 <= 25)
+        return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points (depot included) are not supported "
+                             "(the reference's distance arithmetic differs there)", st->N);
     return DGL_OK;
 }
 

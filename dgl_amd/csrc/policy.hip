@@ -457,11 +457,9 @@ static int check_io(const dgl_policy_io_t *io, int max_n = DGL_MAX_TOKENS) {
 template <int ROWS>
 static int launch_policy(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
     const size_t lds = (size_t)(2 * ROWS * 32 * LDX + 4 * ROWS * 32) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    // (set on every launch: the attribute belongs to the current device's copy of the kernel)
+    if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)policy_kernel_f32<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
     hipLaunchKernelGGL(policy_kernel_f32<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");
     return DGL_OK;

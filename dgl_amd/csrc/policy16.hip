@@ -184,15 +184,21 @@ __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Flo
 #define STAMP() do { } while (0)
 #endif
 
-template <int ROWS>
-__global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
+// GROUPS = 2: a workgroup of 8 waves, two per SIMD.  Waves w and w + 4 own the same output features (the same
+// weight fragments, fetched by both within a few hundred cycles of each other: the second request meets the
+// first one's line in the vector L1) and work on different rows; they run the same program between the same
+// barriers, so one wave's VALU phases (softmax, operand splits, epilogues) and LDS waits interleave with the
+// other's on the SIMD they share.
+template <int ROWS, int GROUPS = 1>
+__global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
     extern __shared__ float lds[];
     constexpr int ROWH = 6 * ARR;                                   // halfs per row: XH XL BH BL CH CL
-    _Float16 *base = reinterpret_cast<_Float16 *>(lds);
-    float *part = lds + ROWS * ROWH / 2;                            // [4][ROWS][32]
-    float *vecs = part + 4 * ROWS * 32;                             // [NVEC] copy of P[PK_VEC0 ..)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * ROWS;
+    const int grp = GROUPS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    _Float16 *base = reinterpret_cast<_Float16 *>(lds) + grp * ROWS * ROWH;
+    float *part = lds + GROUPS * ROWS * ROWH / 2 + grp * 4 * ROWS * 32;   // [GROUPS][4][ROWS][32]
+    float *vecs = lds + GROUPS * ROWS * ROWH / 2 + GROUPS * 4 * ROWS * 32;   // [NVEC] copy of P[PK_VEC0 ..)
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int row0 = (blockIdx.x * GROUPS + grp) * ROWS;
     const int n = io.n;
     // image pointers of row 0 (rows ROWH apart)
     _Float16 *XH = base, *XL = base + ARR, *BH = base + 2 * ARR, *BL = base + 3 * ARR, *CH = base + 4 * ARR,
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
     int nst = 0;
 #endif
     STAMP();
-    for (int i = tid; i < NVEC; i += 256) vecs[i] = P[PK_VEC0 + i];
+    for (int i = threadIdx.x; i < NVEC; i += 256 * GROUPS) vecs[i] = P[PK_VEC0 + i];
     WeightRing<PF16> ring;
     ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM16 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
 
@@ -542,24 +548,27 @@ __global__ __launch_bounds__(256) void policy_kernel_f16(const float *__restrict
     }
 }
 
-template <int ROWS>
+template <int ROWS, int GROUPS>
 static int launch16(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
-    const size_t lds = (size_t)ROWS * 6 * ARR * sizeof(_Float16) + (size_t)(4 * ROWS * 32 + NVEC) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)policy_kernel_f16<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(policy_kernel_f16<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
+    const size_t lds = (size_t)GROUPS * ROWS * 6 * ARR * sizeof(_Float16) + (size_t)(GROUPS * 4 * ROWS * 32 + NVEC) * sizeof(float);
+    // (set on every launch: the attribute belongs to the current device's copy of the kernel)
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)policy_kernel_f16<ROWS, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int per_wg = ROWS * GROUPS;
+    hipLaunchKernelGGL((policy_kernel_f16<ROWS, GROUPS>), dim3((io->R + per_wg - 1) / per_wg), dim3(256 * GROUPS), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");
     return DGL_OK;
 }
 
 int dgl_launch_policy16(const float *packed, const dgl_policy_io_t *io, hipStream_t stream) {
-    // two rows per workgroup share every weight fragment; a single row per workgroup keeps all
-    // 256 CUs busy when there are few rows
-    static const int forced = getenv("DGL_POLICY_ROWS") ? atoi(getenv("DGL_POLICY_ROWS")) : 0;
-    const int rows = forced ? forced : (io->R >= 512 ? 2 : 1);
-    if (rows == 2) return launch16<2>(packed, io, stream);
-    return launch16<1>(packed, io, stream);
+    // shape = 10 * groups + rows per wave.  Two rows per workgroup share every weight fragment; a single row per
+    // workgroup keeps all 256 CUs busy when there are few rows.
+    static const int forced = getenv("DGL_POLICY_SHAPE") ? atoi(getenv("DGL_POLICY_SHAPE")) : 0;
+    const int shape = forced ? forced : (io->R >= 512 ? 12 : 11);
+    switch (shape) {
+    case 11: return launch16<1, 1>(packed, io, stream);
+    case 12: return launch16<2, 1>(packed, io, stream);
+    case 21: return launch16<1, 2>(packed, io, stream);
+    default: return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "DGL_POLICY_SHAPE=%d (11, 12 or 21)", shape);
+    }
 }

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void solution_augment_kernel(const int32_t *__
 extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, int32_t *solution, float *length,
                                          dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && solution && length && B > 0 && N > 1, "bad argument");
+    if (N <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)N * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
     hipFuncSetAttribute(reinterpret_cast<const void *>(nearest_neighbour_kernel<false>),
@@ -177,6 +178,7 @@ extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, 
 extern "C" int dgl_cvrp_nearest_neighbour(const float *xy, const float *demand, int32_t B, int32_t N, int32_t *nodes,
                                           int8_t *flags, dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && demand && nodes && flags && B > 0 && N > 0, "bad argument");
+    if (N + 1 <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)(N + 1) * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
     hipFuncSetAttribute(reinterpret_cast<const void *>(nearest_neighbour_kernel<true>),

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st
     request(j_begin, nxt);
     // The current node and its coordinates are two dependent round trips; they start only now, behind the first
     // group's loads, which do not depend on them.  Wave-uniform values: kept in scalar registers.
-    const int cur = __builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]);
+    // (clamped: a node id outside [0, N) from a faulty caller must not turn into a wild address)
+    const int cur = min(max(__builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]), 0), N - 1);
     const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(tour_in[0]);
     cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void tsp_permute_kernel(dgl_tsp_state_t src, d
                                                          const int32_t *__restrict__ prev_k, int beam, int t) {
     const int r = blockIdx.x;
     const int g = r / beam;
-    const int sr = g * beam + prev_k[r];
+    const int sr = g * beam + min(max(prev_k[r], 0), beam - 1);
     const int N = src.N, W = (N + 63) / 64;
     const size_t so = (size_t)sr * N, d0 = (size_t)r * N;
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
@@ -316,6 +317,11 @@ static int check_tsp_state(const dgl_tsp_state_t *st) {
                   st->B, st->N, st->rows_per_instance);
     DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
     DGL_CHECK_ARG(st->xy && st->avg && st->sd && st->visited && st->tour, "NULL state buffer");
+    // torch.cdist evaluates instances of at most 25 points with the direct formula sqrt(dx^2 + dy^2) instead of the
+    // matrix-product chain implemented here: results would differ from the reference's, so they are refused
+    if (st->N <= 25)
+        return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported (the reference's "
+                             "distance arithmetic differs there)", st->N);
     return DGL_OK;
 }
 

@@ -297,13 +297,16 @@ class CVRPModel(nn.Module):
 
     def forward(self, state, selected_node_list, solution, solution_flag, knn, current_step, depot_knn_nums,
                 selected_flag=None):
-        if self.mode == "train":
-            raise NotImplementedError("the teacher-forced step runs through dgl_amd.train.PolicyTrainer.forward_backward "
-                                      "(gradients live in its flat vector, not in autograd)")
         eng: CvrpEngine = state.engine
-        if knn + depot_knn_nums + 2 > 32:
-            raise NotImplementedError("more than 32 tokens per row (knn + depot_knn + 2) is not supported yet")
         eng.set_knn(knn, depot_knn_nums)
         eng.ensure_neighbourhood()
+        if self.mode == "train":                    # CVRP/CVRPModel.py:311-345
+            from .train import teacher_probability
+            # like the reference, the teacher's entry of ``solution`` (a view) is rewritten to the action id in
+            # place for a move via the depot; CVRPEnv.step rewrites it back (CVRP/CVRPModel.py:329, CVRPEnv.py:619)
+            selected_teacher = solution[:, current_step]
+            is_via_depot = solution_flag[:, current_step] == 1
+            selected_teacher[is_via_depot] += eng.N + 1
+            return selected_teacher, teacher_probability(self, eng, PROBLEM_CVRP, selected_teacher), 1
         eng.forward(self.packed(eng.device))
         return None, eng.dense_probs(), 1

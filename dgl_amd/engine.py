@@ -7,6 +7,7 @@ classes (dgl_amd.tsp / dgl_amd.cvrp / dgl_amd.beamsearch) sit on top of these.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from typing import Dict, Optional
 
@@ -14,6 +15,18 @@ import torch
 
 from . import _lib
 from ._lib import PROBLEM_CVRP, PROBLEM_TSP, MAX_TOKENS, TILE_STRIDE, check, ptr, stream_ptr
+
+def on_own_device(method):
+    """Run an engine method with the engine's device current (kernels, their attributes and the stream handed to
+    the library then all belong to that device, whatever device the caller had selected)."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kw):
+        if torch.cuda.current_device() == self.device.index:
+            return method(self, *args, **kw)
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kw)
+    return wrapper
+
 
 _BLOCKS = ["encoder.layers.0.", "decoder.layers.0.", "decoder.layers.1.", "decoder.layers.2."]
 
@@ -108,7 +121,7 @@ class TspEngine:
         self.rpi = rows_per_instance
         self.R = self.B * rows_per_instance
         self.knn = knn
-        dev = xy.device
+        dev = torch.device("cuda", xy.device.index if xy.device.index is not None else torch.cuda.current_device())
         self.device = dev
         R, N = self.R, self.N
         self.W = (N + 63) // 64
@@ -142,6 +155,7 @@ class TspEngine:
         self.tile_t = -1
         self._alloc_outputs()
 
+    @on_own_device
     def ensure_neighbourhood(self) -> None:
         """Build idx/tile for the current state if the last step did not (dgl_tsp_knn)."""
         if self.tile_t == self.t:
@@ -165,11 +179,13 @@ class TspEngine:
     def state(self):
         return self.bufs[self.cur]
 
+    @on_own_device
     def reset(self) -> None:
         check(self.lib.dgl_tsp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_tsp_reset")
         self.t = 0
         self.tile_t = -1
 
+    @on_own_device
     def step(self, selected: torch.Tensor, want_knn: bool = True) -> None:
         """Apply ``selected`` (int32 [R]) and, unless the tour is complete, build the next neighbourhood."""
         assert selected.dtype == torch.int32 and selected.is_cuda and selected.numel() == self.R
@@ -192,9 +208,11 @@ class TspEngine:
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)
 
+    @on_own_device
     def forward(self, policy: PackedPolicy, **kw) -> None:
         policy_forward(self, policy, self.policy_io(**kw))
 
+    @on_own_device
     def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty(self.R, self.N, dtype=torch.float32, device=self.device)
@@ -203,6 +221,7 @@ class TspEngine:
               "dgl_policy_scatter_probs")
         return out
 
+    @on_own_device
     def permute(self, prev_k: torch.Tensor, beam: int) -> None:
         assert len(self.bufs) == 2 and prev_k.dtype == torch.int32
         src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
@@ -210,12 +229,14 @@ class TspEngine:
                                        self.t, stream_ptr()), "dgl_tsp_permute")
         self.cur = 1 - self.cur
 
+    @on_own_device
     def data(self) -> torch.Tensor:
         out = torch.empty(self.R, self.N, 7, dtype=torch.float32, device=self.device)
         check(self.lib.dgl_tsp_state_data(ctypes.byref(self.state["struct"]), self.t, ptr(out), stream_ptr()),
               "dgl_tsp_state_data")
         return out
 
+    @on_own_device
     def tour_length(self, xy: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Closed-tour length of every row; ``xy`` [B][N][2]: measure on these coordinates instead of the
         engine's own (aug_test evaluates on the original instance, TSP/TSPEnv.py:508-509)."""
@@ -229,6 +250,7 @@ class TspEngine:
         check(self.lib.dgl_tsp_tour_length(ctypes.byref(st), ptr(self.length), stream_ptr()), "dgl_tsp_tour_length")
         return self.length
 
+    @on_own_device
     def greedy_rollout(self, policy: PackedPolicy, start: torch.Tensor) -> torch.Tensor:
         """Whole greedy decode (beam 1): N-1 policy decisions, everything stays on the device."""
         self.reset()
@@ -238,6 +260,7 @@ class TspEngine:
             self.step(self.selected)
         return self.tour_length()
 
+    @on_own_device
     def beam_advance(self, scores: torch.Tensor, beam: int, step: int, prev_k: torch.Tensor, action: torch.Tensor):
         """Beam expansion from the compact per-token probabilities of the last forward()."""
         io = self.policy_io()
@@ -245,6 +268,7 @@ class TspEngine:
                                                 self.N, step, ptr(prev_k), ptr(action), stream_ptr()),
               "dgl_beam_advance_compact")
 
+    @on_own_device
     def step_beam(self, prev_k: torch.Tensor, selected: torch.Tensor, beam: int) -> None:
         """Back-pointer gather and step in one pass over the state (other buffer <- this buffer); the tours are
         rebuilt from the history by ``backtrack``."""
@@ -263,11 +287,13 @@ class TspEngine:
         if more:
             self.tile_t = self.t
 
+    @on_own_device
     def backtrack(self, t_first: int) -> None:
         check(self.lib.dgl_tsp_beam_backtrack(ctypes.byref(self.state["struct"]), ptr(self.hist_node),
                                               ptr(self.hist_parent), t_first, self.t, stream_ptr()),
               "dgl_tsp_beam_backtrack")
 
+    @on_own_device
     def beam_rollout(self, policy: PackedPolicy, start: torch.Tensor, beam: int) -> torch.Tensor:
         """Beam-search decode (TSP/TSPTester.py:145-199) on the compact state: per step the policy, the beam
         expansion over beam*k candidates and one pass over the state that follows the back-pointers while it
@@ -311,7 +337,7 @@ class CvrpEngine:
         self.rpi = rows_per_instance
         self.R = self.B * rows_per_instance
         self.knn, self.depot_knn = knn, depot_knn
-        dev = xy.device
+        dev = torch.device("cuda", xy.device.index if xy.device.index is not None else torch.cuda.current_device())
         self.device = dev
         R = self.R
         self.W = (self.M + 63) // 64
@@ -349,6 +375,7 @@ class CvrpEngine:
         self.tile_t = -1
         self._alloc_outputs()
 
+    @on_own_device
     def ensure_neighbourhood(self) -> None:
         """Build both neighbourhoods and the tile for the current state if the last step did not
         (dgl_cvrp_knn; nudges near-zero capacities exactly once per step, like the reference)."""
@@ -376,11 +403,13 @@ class CvrpEngine:
     def state(self):
         return self.bufs[self.cur]
 
+    @on_own_device
     def reset(self) -> None:
         check(self.lib.dgl_cvrp_reset(ctypes.byref(self.state["struct"]), stream_ptr()), "dgl_cvrp_reset")
         self.t = 0
         self.tile_t = -1
 
+    @on_own_device
     def step(self, action: torch.Tensor, want_knn: bool = True) -> None:
         assert action.dtype == torch.int32 and action.is_cuda and action.numel() == self.R
         self.t += 1
@@ -408,9 +437,11 @@ class CvrpEngine:
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
                              ptr(self.selected) if want_selected else 0)
 
+    @on_own_device
     def forward(self, policy: PackedPolicy, **kw) -> None:
         policy_forward(self, policy, self.policy_io(**kw))
 
+    @on_own_device
     def dense_probs(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         A = 2 * (self.N + 1)
         if out is None:
@@ -420,6 +451,7 @@ class CvrpEngine:
               "dgl_policy_scatter_probs")
         return out
 
+    @on_own_device
     def permute(self, prev_k: torch.Tensor, beam: int) -> None:
         assert len(self.bufs) == 2 and prev_k.dtype == torch.int32
         src, dst = self.bufs[self.cur], self.bufs[1 - self.cur]
@@ -427,12 +459,14 @@ class CvrpEngine:
                                         self.t, stream_ptr()), "dgl_cvrp_permute")
         self.cur = 1 - self.cur
 
+    @on_own_device
     def data(self) -> torch.Tensor:
         out = torch.empty(self.R, self.M, 8, dtype=torch.float32, device=self.device)
         check(self.lib.dgl_cvrp_state_data(ctypes.byref(self.state["struct"]), self.t, ptr(out), stream_ptr()),
               "dgl_cvrp_state_data")
         return out
 
+    @on_own_device
     def route_length(self, xy: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Route length of every row; ``xy`` [B][N+1][2]: measure on these coordinates instead of the engine's
         own (aug_test evaluates on the original instance, CVRP/CVRPEnv.py:864-865)."""
@@ -450,6 +484,7 @@ class CvrpEngine:
 
     tour_length = route_length
 
+    @on_own_device
     def greedy_rollout(self, policy: PackedPolicy, start_action: torch.Tensor) -> torch.Tensor:
         self.reset()
         self.step(start_action)
@@ -458,12 +493,14 @@ class CvrpEngine:
             self.step(self.selected)
         return self.route_length()
 
+    @on_own_device
     def beam_advance(self, scores: torch.Tensor, beam: int, step: int, prev_k: torch.Tensor, action: torch.Tensor):
         io = self.policy_io()
         check(self.lib.dgl_beam_advance_compact(ctypes.byref(io), ptr(self.prob), ptr(scores), self.R // beam, beam,
                                                 2 * (self.N + 1), step, ptr(prev_k), ptr(action), stream_ptr()),
               "dgl_beam_advance_compact")
 
+    @on_own_device
     def step_beam(self, prev_k: torch.Tensor, action: torch.Tensor, beam: int) -> None:
         """Back-pointer gather and step in one pass over the state (other buffer <- this buffer); nodes and flags
         are rebuilt from the history by ``backtrack``."""
@@ -483,11 +520,13 @@ class CvrpEngine:
         if more:
             self.tile_t = self.t
 
+    @on_own_device
     def backtrack(self, t_first: int) -> None:
         check(self.lib.dgl_cvrp_beam_backtrack(ctypes.byref(self.state["struct"]), ptr(self.hist_action),
                                                ptr(self.hist_parent), t_first, self.t, stream_ptr()),
               "dgl_cvrp_beam_backtrack")
 
+    @on_own_device
     def beam_rollout(self, policy: PackedPolicy, start_action: torch.Tensor, beam: int) -> torch.Tensor:
         """Beam-search decode (CVRP/CVRPTester.py:147-227) on the compact state; the step follows the
         back-pointers while it updates, nodes and flags are rebuilt from the history at the end."""

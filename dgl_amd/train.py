@@ -130,6 +130,63 @@ class PolicyTrainer:
                                      stream_ptr()), "dgl_adam_step")
 
 
+class _TeacherProbability(torch.autograd.Function):
+    """The reference's ``model(...)`` in mode 'train' as one differentiable node: forward returns the teacher's
+    probability per row [R, 1] (TSP/TSPModel.py:206-217, CVRP/CVRPModel.py:311-345), backward hands the
+    parameters' gradients to autograd, so that the reference's own loop
+        loss = -prob.type(torch.float64).log().mean(); model.zero_grad(); loss.backward(); optimizer.step()
+    (CVRP/CVRPTrainer.py:268-272) runs unchanged on a torch optimizer over ``model.parameters()``.
+
+    The device kernel evaluates forward and backward in one call and differentiates exactly that loss
+    (-mean log p over the rows); backward() checks that the incoming gradient is c * d(-mean log p)/dp for one
+    constant c (c = 1 for the reference's loss) and scales by it; any other loss is refused."""
+
+    @staticmethod
+    def forward(ctx, engine, problem, teacher, keys, *params):
+        lib = _lib.load()
+        dev = engine.device
+        for k, p in zip(keys, params):
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError(f"parameter {k} must be a contiguous float32 tensor on {dev} (model.to(device))")
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads, off = {}, 0
+        for k, p in zip(keys, params):
+            grads[k] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        w = weights_struct({k: p.detach() for k, p in zip(keys, params)}, problem)
+        g = weights_struct(grads, problem)
+        io = engine.policy_io(want_logits=False, want_prob=False, want_selected=False)
+        ws = general_workspace(engine, io.R, io.n)
+        prob = torch.empty(io.R, dtype=torch.float32, device=dev)
+        teacher = teacher.to(device=dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            check(lib.dgl_policy_general(ctypes.byref(w), ctypes.byref(g), ctypes.byref(io), ptr(teacher), 1.0 / io.R,
+                                         ptr(ws), ptr(prob), stream_ptr()), "dgl_policy_general")
+        ctx.grads = [grads[k] for k in keys]
+        ctx.rows = io.R
+        ctx.save_for_backward(prob)
+        return prob.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (prob,) = ctx.saved_tensors
+        # the kernel's gradients are those of sum_r (1/R)(-log p_r): they answer d loss / d p_r = -1 / (R p_r)
+        c = grad_out.reshape(-1).double() * prob.double() * (-float(ctx.rows))
+        scale = float(c.mean())
+        if not torch.allclose(c, torch.full_like(c, scale), rtol=1e-4, atol=0.0):
+            raise NotImplementedError("the device backward pass differentiates -log(prob).mean() (times a constant) only")
+        out = ctx.grads if scale == 1.0 else [g * scale for g in ctx.grads]
+        return (None, None, None, None, *out)
+
+
+def teacher_probability(model: torch.nn.Module, engine, problem: int, teacher: torch.Tensor) -> torch.Tensor:
+    """Probability of the teacher's action per row, [R, 1], differentiable with respect to ``model``'s parameters
+    (the two tensors the forward pass never uses get no gradient, as in the reference)."""
+    named = [(k, p) for k, p in model.named_parameters() if not k.startswith(UNUSED)]
+    keys = [k for k, _ in named]
+    return _TeacherProbability.apply(engine, problem, teacher, keys, *[p for _, p in named])
+
+
 def world_size() -> int:
     d = torch.distributed
     return d.get_world_size() if d.is_available() and d.is_initialized() else 1

@@ -97,18 +97,22 @@ class LogData:
 
 
 class MultiStepLR:
-    """lr = base * gamma^(milestones passed); the trainers call step() once per saved checkpoint
-    (every fifth epoch, CVRP/CVRPTrainer.py:126-136), not once per epoch."""
+    """torch.optim.lr_scheduler.MultiStepLR in its chainable form: a step multiplies the CURRENT learning rate by
+    gamma (once per occurrence of the new epoch count among the milestones) and leaves it alone otherwise, so a
+    learning rate restored from a checkpoint's optimizer state is kept on resume, as in the reference.  The trainers
+    call step() once per saved checkpoint (every fifth epoch, CVRP/CVRPTrainer.py:126-136), not once per epoch, and
+    set last_epoch = epoch - 1 after loading a checkpoint (TSP/TSPTrainer.py:75-84)."""
 
-    def __init__(self, trainer: PolicyTrainer, milestones, gamma):
+    def __init__(self, trainer, milestones, gamma):
         self.trainer, self.milestones, self.gamma = trainer, sorted(milestones), gamma
         self.base_lr = trainer.lr
         self.last_epoch = 0
 
     def step(self):
         self.last_epoch += 1
-        passed = sum(1 for m in self.milestones if m <= self.last_epoch)
-        self.trainer.lr = self.base_lr * self.gamma ** passed
+        hits = self.milestones.count(self.last_epoch)
+        if hits:
+            self.trainer.lr = self.trainer.lr * self.gamma ** hits
 
     def state_dict(self):
         return {"milestones": {m: 1 for m in self.milestones}, "gamma": self.gamma, "base_lrs": [self.base_lr],

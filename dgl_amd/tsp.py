@@ -226,11 +226,12 @@ class TSPModel(nn.Module):
         return self._packed
 
     def forward(self, state, selected_node_list, solution, knn, current_step):
-        if self.mode == "train":
-            raise NotImplementedError("the teacher-forced step runs through dgl_amd.train.PolicyTrainer.forward_backward "
-                                      "(gradients live in its flat vector, not in autograd)")
         eng: TspEngine = state.engine
         eng.set_knn(knn)
         eng.ensure_neighbourhood()
+        if self.mode == "train":                    # TSP/TSPModel.py:206-217
+            from .train import teacher_probability
+            selected_teacher = solution[:, current_step]
+            return selected_teacher, teacher_probability(self, eng, PROBLEM_TSP, selected_teacher), 1
         eng.forward(self.packed(eng.device))
         return None, eng.dense_probs(), 1

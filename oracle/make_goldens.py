@@ -320,6 +320,9 @@ TRAINED_CASES = {
     "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
     "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
     "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),
+    # more than 32 tokens per row: the CVRPLIB setting (CVRP/test_cvrplib.py:326-327) and a TSP row of 51 tokens
+    "cvrp_n200_b4_k50_nn": ("cvrp", dict(seed=321, B=4, N=200, knn=50, depot_knn=50)),
+    "tsp_n200_b4_k50_nn": ("tsp", dict(seed=321, B=4, N=200, knn=50)),
 }
 
 CASES = {

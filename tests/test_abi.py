@@ -43,3 +43,19 @@ def test_every_entry_point_cites_the_reference():
         pos = text.index(name + "(")
         comment = text[text.rfind("/*", 0, pos):pos]
         assert re.search(r"\.py:\d+", comment), f"{name} has no reference file:line citation"
+
+
+def test_instances_of_at_most_25_points_are_refused():
+    """torch.cdist takes its direct sqrt(dx^2 + dy^2) path for at most 25 points; the kernels implement the
+    matrix-product arithmetic only, so such instances are refused before anything is launched."""
+    import ctypes
+    from dgl_amd import _lib
+    lib = _lib.load()
+    fake = 4096                                   # never dereferenced: the size check comes first
+    st = _lib.TspState(2, 20, 1, 2, fake, fake, fake, fake, fake)
+    assert lib.dgl_tsp_reset(ctypes.byref(st), None) == -2                  # DGL_ERR_UNSUPPORTED
+    assert b"25 points" in lib.dgl_last_error_string()
+    cv = _lib.CvrpState(2, 20, 1, 2, fake, fake, fake, fake, fake, fake, fake, fake, 0)      # 21 points with the depot
+    assert lib.dgl_cvrp_reset(ctypes.byref(cv), None) == -2
+    assert lib.dgl_tsp_nearest_neighbour(fake, 2, 25, fake, fake, None) == -2
+    assert lib.dgl_cvrp_nearest_neighbour(fake, fake, 2, 24, fake, fake, None) == -2

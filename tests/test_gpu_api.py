@@ -49,7 +49,7 @@ def _cvrp_tester(case, weights, beam):
     return t
 
 
-@pytest.mark.parametrize("name", ["tsp_n100_b64_nn", "tsp_n200_b2_beam8_nn", "tsp_n60_b2_beam4_pomo2"])
+@pytest.mark.parametrize("name", ["tsp_n100_b64_nn", "tsp_n200_b2_beam8_nn", "tsp_n60_b2_beam4_pomo2", "tsp_n200_b4_k50_nn"])
 def test_tsp_reference_protocol_and_fast_path(name, device):
     case, weights = load_golden(name)
     beam = int(case["meta/beam"])
@@ -72,7 +72,7 @@ def test_tsp_reference_protocol_and_fast_path(name, device):
     assert abs(shortest.mean().item() - best) < 2e-3 * best
 
 
-@pytest.mark.parametrize("name", ["cvrp_n100_b64_nn", "cvrp_n150_b2_beam8_nn"])
+@pytest.mark.parametrize("name", ["cvrp_n100_b64_nn", "cvrp_n150_b2_beam8_nn", "cvrp_n200_b4_k50_nn"])
 def test_cvrp_reference_protocol_and_fast_path(name, device):
     case, weights = load_golden(name)
     beam = int(case["meta/beam"])
@@ -130,3 +130,61 @@ def test_tester_run_with_files(device, tmp_path):
     t = TSPTester(env_params, dict(MODEL_PARAMS, append_information=TSP_INFO), None, tester_params, None)
     gap = t.run()
     assert 5.0 < t.score < 20.0 and abs(gap) < 0.2
+
+
+def test_reference_training_loop_on_the_swapped_in_model(device, monkeypatch):
+    """The reference's own _train_one_batch loop (CVRP/CVRPTrainer.py:232-282), statement for statement, on this
+    build's CVRPEnv / CVRPModel with a torch optimizer: model(...) in mode 'train' returns (teacher, prob, 1) and
+    loss.backward() fills the parameters' .grad.  Compared with the batch captured from the reference."""
+    from conftest import GOLDEN
+    from dgl_amd import cvrp as C
+    g = np.load(os.path.join(GOLDEN, "train_cvrp_n40_b4.npz"))
+    w0 = np.load(os.path.join(GOLDEN, "weights_cvrp_init789.npz"))
+    knn, depot_knn_nums = int(g["meta/knn"]), int(g["meta/depot_knn"])
+    monkeypatch.setattr(C, "mix_augment", lambda xy: xy)            # the golden holds the augmented coordinates
+    env = C.CVRPEnv(mode="train", pomo_size=1, append_information=CVRP_INFO, knn=knn, depot_knn=depot_knn_nums,
+                    device=str(device))
+    B, M = g["aug_xy"].shape[:2]
+    env.batch_size, env.problem_size = B, M - 1
+    env.depot_node_xy = torch.from_numpy(g["aug_xy"])
+    env.depot_node_demand = torch.from_numpy(g["problems"][:, :, 2])
+    env.solution = torch.from_numpy(g["solution"]).to(device)
+    env.solution_flag = torch.from_numpy(g["solution_flag"]).to(device)
+    solution0 = env.solution.clone()
+    model = C.CVRPModel(**dict(MODEL_PARAMS, mode="train", append_information=CVRP_INFO)).to(device)
+    model.load_state_dict({k: torch.from_numpy(w0[k]) for k in w0.files})
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)      # CVRP/train.py:49-54
+
+    model.train()
+    env.reset("train")
+    prob_list = torch.ones(size=(B, 0), device=device)
+    state, reward, done = env.pre_step()
+    model.mode = "train"
+    model.pre_forward(env.dis_matrix, env.batch_size)
+    current_step = 0
+    losses = []
+    while not done:
+        if current_step == 0:
+            selected = env.solution[:, 0]
+            prob = torch.ones(env.solution.shape[0], 1, device=device)
+            is_via_depot = env.solution_flag[:, current_step] == 1
+            selected[is_via_depot] += (env.problem_size + 1)
+        else:
+            selected, prob, probs = model(state, env.selected_node_list, env.solution, env.solution_flag, knn,
+                                          current_step, depot_knn_nums)
+            loss_mean = -prob.type(torch.float64).log().mean()
+            model.zero_grad()
+            loss_mean.backward()
+            optimizer.step()
+            losses.append(float(loss_mean))
+        current_step += 1
+        state, reward, done = env.step(selected)
+        prob_list = torch.cat((prob_list, prob.detach()), dim=1)
+    assert torch.equal(env.solution, solution0)              # the in-place rewrites of the teacher's entries cancel
+    assert model.decoder.k_1.weight.grad is None             # never used by the forward pass, as in the reference
+    probs = prob_list[:, 1:].t().cpu().numpy()
+    rel = np.abs(probs - g["prob"]) / g["prob"]
+    print(f"reference loop on the swapped-in model: {len(losses)} Adam steps, teacher probabilities max relative "
+          f"difference {rel.max():.2e}, median {np.median(rel):.2e}")
+    np.testing.assert_allclose(np.array(losses), g["loss"], rtol=2e-3, atol=2e-4)
+    assert np.median(rel) < 1e-4 and rel.max() < 2e-2

@@ -34,21 +34,26 @@ def test_reset_matches_golden(name, device):
     assert (eng.state["capacity"].cpu().numpy() == 1.0).all()
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n100_b64_nn"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n100_b64_nn", "cvrp_n120_b2_k20",
+                                  "cvrp_n200_b4_k50_nn"])
 def test_teacher_forced_steps_match_golden(name, device):
+    """Drive the state with the reference's own route; at every step: both index sets bit-exact, capacities
+    bit-exact, logits within 1e-3 of the row's largest |logit| while more than 8 nodes are left, and for ALL steps
+    (the last 8 included) the tile columns that do not come from the avg / sd recurrences within 2e-5 and the greedy
+    pick equal to the reference's action wherever the reference's own decision margin exceeds 2e-3 of the row's
+    largest |logit|.  Rows of more than 32 tokens (knn = depot_knn = 20 / 50) run on the general path."""
     from dgl_amd._lib import PROBLEM_CVRP, TILE_STRIDE
     from dgl_amd.engine import PackedPolicy
     case, weights = load_golden(name)
-    if int(case["meta/knn"]) + int(case["meta/depot_knn"]) + 2 > 32:
-        pytest.skip("more than 32 tokens per row")
     eng = _engine(case, device)
     pol = PackedPolicy(weights, PROBLEM_CVRP, device)
-    act = torch.from_numpy(_actions(case)).to(device)
+    actions = _actions(case)
+    act = torch.from_numpy(actions).to(device)
     N = eng.N
     eng.reset()
-    max_logit_err = max_tile_err = max_cap_err = tail_logit_err = 0.0
+    max_logit_err = max_tile_err = max_cap_err = tail_logit_err = max_exact_col_err = 0.0
     tile_errs = []
-    agree = total = 0
+    agree = total = decided = decided_same = tail_decided = tail_same = 0
     for t in range(1, N):
         eng.step(act[:, t - 1].contiguous())
         kl, kd = eng.kl, eng.kd
@@ -58,6 +63,11 @@ def test_teacher_forced_steps_match_golden(name, device):
         assert (il[:, kl:] == -1).all() and (idp[:, kd:] == -1).all()
         eng.forward(pol)
         n = kl + kd + 2
+        tail = N - t <= 8
+        sel = eng.selected.cpu().numpy()
+        same = sel == actions[:, t]
+        agree += int(same.sum())
+        total += eng.R
         if "capacity" in case:
             cap = eng.state["capacity"].cpu().numpy()
             max_cap_err = max(max_cap_err, float(np.abs(cap - case["capacity"][t - 1]).max()))
@@ -72,28 +82,47 @@ def test_teacher_forced_steps_match_golden(name, device):
             # The avg/sd recurrences amplify a 1-ulp difference by ~N/u (u nodes left), and with <= 3
             # nodes left the running std is analytically ~0, i.e. the reference's own value is rounding
             # noise that min-max normalisation over 2-4 tokens blows up to 0/1.  The 1e-3 bound is
-            # therefore asserted while more than 8 nodes are left; the tail is reported.
-            if N - t > 8:
+            # therefore asserted while more than 8 nodes are left; for the tail see the decision check below.
+            if not tail:
                 max_logit_err = max(max_logit_err, err)
             else:
                 tail_logit_err = max(tail_logit_err, err)
+            # decision margin of the reference: gap between its two most probable actions in logit units
+            # (log p differences are logit differences), relative to the row's largest |logit|
+            p = np.sort(case["p"][t - 1][:, :kl + kd].astype(np.float64), axis=1)
+            if p.shape[1] >= 2:
+                margin = (np.log(p[:, -1]) - np.log(np.maximum(p[:, -2], 1e-300))) / scale[:, 0]
+                clear = margin > 2e-3
+            else:
+                clear = np.ones(eng.R, bool)
+            decided += int(clear.sum())
+            decided_same += int((clear & same).sum())
+            if tail:
+                tail_decided += int(clear.sum())
+                tail_same += int((clear & same).sum())
         if "tile" in case:
             tile = eng.tile.cpu().numpy().reshape(eng.R, -1, TILE_STRIDE)[:, :n, :9]
             gt = case["tile"][t - 1][:, :n * 9].reshape(eng.R, n, 9)
-            if N - t > 8:
+            exact_cols = [0, 1, 2, 3, 6, 7, 8]              # x, y, demand, d, sin, cos, group flag (not avg, sd)
+            max_exact_col_err = max(max_exact_col_err, float(np.abs(tile[:, :, exact_cols] - gt[:, :, exact_cols]).max()))
+            if not tail:
                 max_tile_err = max(max_tile_err, float(np.abs(tile - gt).max()))
                 tile_errs.append(np.abs(tile - gt).ravel())
-        sel = eng.selected.cpu().numpy()
-        agree += int((sel == _actions(case)[:, t]).sum())
-        total += eng.R
-    print(f"{name}: max rel logit err {max_logit_err:.2e} (last 8 steps {tail_logit_err:.2e}), max tile err {max_tile_err:.2e}, capacity err "
-          f"{max_cap_err:.1e}, greedy pick agreement {agree}/{total}")
+    print(f"{name}: max rel logit err {max_logit_err:.2e} (last 8 steps {tail_logit_err:.2e}), max tile err {max_tile_err:.2e} "
+          f"(columns without avg/sd, all steps: {max_exact_col_err:.2e}), capacity err {max_cap_err:.1e}, greedy pick agreement "
+          f"{agree}/{total}; where the reference's margin > 2e-3: {decided_same}/{decided} (last 8 steps {tail_same}/{tail_decided})")
     assert max_logit_err < 1e-3
     assert max_cap_err == 0.0
+    if "logits" in case:
+        assert decided_same == decided, "a greedy pick differs where the reference's decision margin exceeds 2e-3"
+        # the tail's logit error is bounded by what min-max normalisation can do to a noise-level sd column: one
+        # column of 0/1 flips, i.e. O(1) of the row's scale; it is recorded here and must stay below 2
+        assert tail_logit_err < 2.0, tail_logit_err
     if tile_errs:
         errs = np.concatenate(tile_errs)
         assert np.quantile(errs, 0.999) < 2e-5
         assert max_tile_err < 5e-3
+        assert max_exact_col_err < 2e-5
 
 
 @pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8"])

@@ -26,7 +26,7 @@ def test_reset_matches_golden(name, device):
     np.testing.assert_allclose(sd, case["std0"], rtol=3e-7, atol=0)
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn", "tsp_n200_b4_k50_nn"])
 def test_teacher_forced_steps_match_golden(name, device):
     """Drive the state with the reference's own tour; at every step compare the kNN index
     sets (bit-exact), the normalised token tile and the logits (1e-3 relative)."""

@@ -152,3 +152,34 @@ def test_gradient_allreduce_gloo_world2():
     ref = torch.cat([v.grad.reshape(-1) for v in orc.w.values() if v.grad is not None]).numpy()
     assert np.array_equal(out[0], out[1])
     np.testing.assert_allclose(out[0], ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_multistep_lr_follows_torch_on_a_fresh_run_and_on_resume():
+    """The trainers' scheduler against torch.optim.lr_scheduler.MultiStepLR driven the way the reference drives it:
+    fresh run, and resume (optimizer state restored, last_epoch = epoch - 1 as TSP/TSPTrainer.py:75-84 sets it)."""
+    import types
+    import torch
+    from dgl_amd.trainer import MultiStepLR
+    milestones, gamma, base = list(range(1, 200)), 0.97, 1e-4          # CVRP/train.py:55-58
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=base)
+    ref = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=milestones, gamma=gamma)
+    mine_tr = types.SimpleNamespace(lr=base)
+    mine = MultiStepLR(mine_tr, milestones, gamma)
+    for _ in range(10):                                                # ten saved checkpoints = fifty epochs
+        opt.step(); ref.step(); mine.step()
+        assert abs(mine_tr.lr - opt.param_groups[0]["lr"]) <= 1e-12 * base
+    saved_lr = opt.param_groups[0]["lr"]
+    # resume at epoch 50: the checkpoint's optimizer state carries the lr, the trainer pokes last_epoch
+    opt2 = torch.optim.Adam([p], lr=base)
+    ref2 = torch.optim.lr_scheduler.MultiStepLR(opt2, milestones=milestones, gamma=gamma)
+    opt2.load_state_dict(opt.state_dict())
+    ref2.last_epoch = 50 - 1
+    tr2 = types.SimpleNamespace(lr=base)
+    mine2 = MultiStepLR(tr2, milestones, gamma)
+    tr2.lr = saved_lr                                                  # PolicyTrainer.load_optimizer_state_dict
+    mine2.last_epoch = 50 - 1
+    for _ in range(3):
+        opt2.step(); ref2.step(); mine2.step()
+        assert abs(tr2.lr - opt2.param_groups[0]["lr"]) <= 1e-12 * base
+    assert abs(tr2.lr - saved_lr * gamma ** 3) <= 1e-12 * base
