@@ -94,17 +94,22 @@ def _floor_small(p: Tensor) -> Tensor:
     return out
 
 
-def beam_advance(log_probs: Tensor, scores: Tensor, step: int, beam: int, action_size: int
+def beam_advance(log_probs: Tensor, scores: Tensor, step: int, beam: int, action_size: int, stable: bool = False
                  ) -> Tuple[Tensor, Tensor, Tensor]:
     """utils/beamsearch.py:65-99.  log_probs [G, beam, A]; scores [G, beam].
-    Returns (new scores [G,beam], prev_k [G,beam], action [G,beam])."""
+    Returns (new scores [G,beam], prev_k [G,beam], action [G,beam]).  ``stable``: equal values are taken in
+    order of their flat index (the reference's torch.topk leaves the order of ties to its implementation)."""
     if step >= 2:
         lk = log_probs + scores.unsqueeze(2).expand_as(log_probs)
     else:
         lk = log_probs.clone()
         lk[:, 1:] = -1e20
     lk = lk.reshape(lk.shape[0], -1)
-    best, ids = lk.topk(beam, 1, True, True)
+    if stable:
+        best, ids = lk.sort(dim=1, descending=True, stable=True)
+        best, ids = best[:, :beam], ids[:, :beam]
+    else:
+        best, ids = lk.topk(beam, 1, True, True)
     prev_k = torch.div(ids, action_size, rounding_mode="trunc")
     action = ids - prev_k * action_size
     return best, prev_k, action
@@ -149,6 +154,29 @@ def cvrp_route_length(xy: Tensor, nodes: Tensor, flags: Tensor) -> Tensor:
 # --------------------------------------------------------------------------
 # TSP
 # --------------------------------------------------------------------------
+def chain_cdist(p: Tensor) -> Tensor:
+    """torch.cdist(p, p) for more than 25 points per instance, restated with elementwise IEEE operations so that the
+    result does not depend on which matrix-product kernel the BLAS library picks for this CPU and this size:
+    [-2 p_i, |p_i|^2, 1] . [p_j, 1, |p_j|^2] accumulated left to right, first product rounded, every later term one
+    fused multiply-add, then sqrt(max(., 0)).  binary32 FMAs are evaluated in binary64 (the product is exact there)
+    and rounded once; the square root is the correctly rounded one.  p [B, M, C], C = 2 or 3 (training reset:
+    x, y, demand; CVRP/CVRPEnv.py:519).  In the container that generated the golden vectors this equals torch.cdist
+    except where that build's vectorised float sqrt is 1 ulp off (about 0.6 % of the entries; tests/test_oracle_c.py)."""
+    p = p.to(torch.float32)
+    sq = p * p
+    n = sq[..., 0] + sq[..., 1]
+    for c in range(2, p.shape[-1]):
+        n = n + sq[..., c]
+    a = (-2.0 * p).double()
+    b = p.double()
+    acc = (a[:, :, None, 0] * b[:, None, :, 0]).float()
+    for c in range(1, p.shape[-1]):
+        acc = (a[:, :, None, c] * b[:, None, :, c] + acc.double()).float()
+    acc = acc + n[:, :, None]
+    acc = acc + n[:, None, :]
+    return acc.clamp_min(0).double().sqrt().float()
+
+
 class TSPOracle:
     """State + policy of the TSP path.  ``w`` is a reference-format state_dict."""
 
@@ -159,12 +187,13 @@ class TSPOracle:
         self.knn = knn
 
     # -- environment ------------------------------------------------------
-    def reset(self, xy: Tensor, rows_per_instance: int = 1) -> None:
+    def reset(self, xy: Tensor, rows_per_instance: int = 1, chain: bool = False) -> None:
+        """``chain``: build the matrix with chain_cdist instead of torch.cdist (same arithmetic on every CPU)."""
         self.B, self.N = xy.shape[0], xy.shape[1]
         self.rpi = rows_per_instance
         self.R = self.B * rows_per_instance
         self.xy_inst = xy
-        self.dis = torch.cdist(xy, xy, p=2)
+        self.dis = chain_cdist(xy) if chain else torch.cdist(xy, xy, p=2)
         self.xy = xy.repeat_interleave(rows_per_instance, 0)
         self.avg = self.dis.mean(dim=-1).repeat_interleave(rows_per_instance, dim=0)
         self.std = self.dis.std(unbiased=False, dim=-1).repeat_interleave(rows_per_instance, dim=0)
@@ -292,16 +321,18 @@ class CVRPOracle:
         self.depot_knn = depot_knn
 
     def reset(self, depot_xy: Tensor, node_xy: Tensor, demand: Tensor, rows_per_instance: int = 1,
-              train: bool = False) -> None:
+              train: bool = False, chain: bool = False) -> None:
         """depot_xy [B,2]; node_xy [B,N,2]; demand [B,N] (already / capacity).  ``train``: the distance
-        matrix of reset('train') (CVRP/CVRPEnv.py:519), cdist over (x, y, demand)."""
+        matrix of reset('train') (CVRP/CVRPEnv.py:519), cdist over (x, y, demand).  ``chain``: build the matrix
+        with chain_cdist instead of torch.cdist (same arithmetic on every CPU)."""
         B, N = node_xy.shape[0], node_xy.shape[1]
         self.B, self.N, self.rpi = B, N, rows_per_instance
         self.R = B * rows_per_instance
         xy = torch.cat((depot_xy[:, None, :], node_xy), dim=1)
         dem = torch.cat((torch.zeros(B, 1), demand), dim=1)
         self.problems = torch.cat((xy, dem[:, :, None]), dim=2)
-        self.dis = (torch.cdist(self.problems, self.problems, p=2) if train else torch.cdist(xy, xy, p=2)).to(torch.float32)
+        pts = self.problems if train else xy
+        self.dis = (chain_cdist(pts) if chain else torch.cdist(pts, pts, p=2)).to(torch.float32)
         self.xy = xy.repeat_interleave(rows_per_instance, 0)
         self.demand = dem.repeat_interleave(rows_per_instance, 0)
         self.capacity = torch.ones(self.R)

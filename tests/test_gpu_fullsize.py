@@ -119,3 +119,160 @@ def test_cvrp1000_b512_properties(device):
     np.testing.assert_allclose(length, host, rtol=2e-6)
     length2 = eng.greedy_rollout(pol, start).cpu().numpy()
     assert np.array_equal(eng.state["nodes"].cpu().numpy(), nodes) and np.array_equal(length2, length)
+
+
+def test_config5_cvrp5000_training_step_at_size(device):
+    """Configuration 5 at its own size: CVRP with 5000 customers, knn = depot_knn = 100 (202 tokens per row), the
+    training reset's distances over (x, y, demand).  Two instances are walked through a random feasible route; at
+    steps 1 / 2500 / 4900 the running statistics, both neighbourhoods (the general selection, k > 64, over 5001 keys),
+    the token tile, the teacher's probability and the gradients of the teacher-forced step are compared with the
+    oracle (its dense 5001 x 5001 matrix, full argsort and autograd); at step 4990 the neighbourhoods once more; then
+    one Adam update against torch.optim.Adam.  The oracle's matrix is built by chain_cdist: torch.cdist's own
+    accumulation order at this size depends on the BLAS kernel chosen for the host CPU (on the GPU box 18 % of the
+    entries come out 1 ulp away from what the same call returns where the golden vectors were made)."""
+    from dgl_amd._lib import PROBLEM_CVRP, TILE_STRIDE
+    from dgl_amd.engine import CvrpEngine
+    from dgl_amd.train import PolicyTrainer
+    from oracle.dgl_oracle import CVRPOracle, enable_grad, random_weights, train_forward_backward
+    from test_gpu_train import _compare_grads
+    Bc, Nc, knn = 2, 5000, 100
+    Mc = Nc + 1
+    gen = torch.Generator().manual_seed(55)
+    depot, nodes = torch.rand(Bc, 2, generator=gen), torch.rand(Bc, Nc, 2, generator=gen)
+    demand = torch.randint(1, 200, (Bc, Nc), generator=gen) / 500.0
+    w = random_weights("CVRP", 55)
+    orc = CVRPOracle(w, knn, knn)
+    orc.w = enable_grad(w)
+    orc.reset(depot, nodes, demand, train=True, chain=True)
+    xy = torch.cat((depot[:, None, :], nodes), 1)
+    dem = torch.cat((torch.zeros(Bc, 1), demand), 1)
+    eng = CvrpEngine(xy.to(device), dem.to(device), 1, knn, knn, demand_in_distance=True)
+    tr = PolicyTrainer(w, PROBLEM_CVRP, device)
+    eng.reset()
+    np.testing.assert_allclose(eng.state["avg"].cpu().numpy(), orc.avg.numpy(), rtol=3e-7)
+    np.testing.assert_allclose(eng.state["sd"].cpu().numpy(), orc.std.numpy(), rtol=3e-7)
+    order = torch.stack([torch.randperm(Nc, generator=gen) + 1 for _ in range(Bc)])
+    cap = np.ones(Bc, np.float32)
+    dem_np = dem.numpy()
+    checked = 0
+    with torch.no_grad():
+        for t in range(1, 4991):
+            act = torch.zeros(Bc, dtype=torch.long)
+            for b in range(Bc):
+                node = int(order[b, t - 1])
+                via = t == 1 or cap[b] + np.float32(1e-6) < dem_np[b, node]
+                cap[b] = np.float32(1.0) - dem_np[b, node] if via else cap[b] - dem_np[b, node]
+                act[b] = node + (Mc if via else 0)
+            check = t in (1, 2500, 4900, 4990)
+            if check and t > 1:
+                # Two float trajectories that start 1 ulp apart (the reset's summation order) drift apart like a random
+                # walk: every step rounds independently, and the recurrences amplify by (u+1)/u.  Bound that drift,
+                # then put the device on the oracle's state so that the compared step starts from equal inputs.
+                tol = (4e-7 + 3e-7 * np.sqrt(t)) * Mc / (Mc - t)
+                np.testing.assert_allclose(eng.state["avg"].cpu().numpy(), orc.avg.numpy(), rtol=tol, atol=tol)
+                np.testing.assert_allclose(eng.state["sd"].cpu().numpy(), orc.std.numpy(), rtol=tol, atol=tol)
+                eng.state["avg"].copy_(orc.avg)
+                eng.state["sd"].copy_(orc.std)
+            eng.step(act.to(device=device, dtype=torch.int32))
+            orc.step(act.clone())
+            assert np.array_equal(orc.capacity.numpy(), cap)
+            if check:
+                assert cap.min() >= 1e-5                       # (no capacity nudge at a compared step)
+                # one step from equal inputs: same operations, the oracle's float sqrt may be 1 ulp off
+                tol = 4e-7 if t == 1 else 1.3e-7
+                unv = np.ones((Bc, Mc), bool)
+                unv[np.arange(Bc)[:, None], orc.nodes.numpy()] = False
+                np.testing.assert_allclose(eng.state["avg"].cpu().numpy()[unv], orc.avg.numpy()[unv], rtol=tol)
+                np.testing.assert_allclose(eng.state["sd"].cpu().numpy()[unv], orc.std.numpy()[unv], rtol=tol, atol=1e-9)
+                il, idp = orc.knn_indices()
+                kl, kd = il.shape[1], idp.shape[1]
+                assert kd == min(knn, Nc - t) and eng.kl == kl and eng.kd == kd
+                assert np.array_equal(eng.idx_last.cpu().numpy()[:, :kl], il.numpy()), t
+                assert np.array_equal(eng.idx_dep.cpu().numpy()[:, :kd], idp.numpy()), t
+                if t == 4990:
+                    continue
+                n = kl + kd + 2
+                tile_ref, _, _ = orc.tiles(il, idp)
+                tile = eng.tile.cpu().numpy().reshape(Bc, -1, TILE_STRIDE)[:, :n, :9]
+                exact_cols = [0, 1, 2, 3, 6, 7, 8]
+                assert np.abs(tile[:, :, exact_cols] - tile_ref.numpy()[:, :, exact_cols]).max() < 2e-5
+                assert np.abs(tile - tile_ref.numpy()).max() < 5e-3
+                # the teacher-forced step: one direct move and one move via the depot
+                teacher = torch.stack((il[0, 3], idp[1, 5] + Mc))
+                with torch.enable_grad():
+                    prob_ref, loss_ref = train_forward_backward(orc, teacher)
+                tr.zero_grad()
+                prob = tr.forward_backward(eng, teacher)
+                np.testing.assert_allclose(prob.cpu().numpy(), prob_ref.numpy(), rtol=1e-3)
+                worst = _compare_grads(tr, orc, 3e-3)
+                print(f"CVRP-5000 step {t}: n={n} tokens, loss {loss_ref:.5f}, worst relative gradient error {worst:.2e}")
+                checked += 1
+    assert checked == 3
+    # one Adam update from the last compared gradients (CVRP/train.py:49-54)
+    keys = tr.keys
+    params = [orc.w[k] for k in keys]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-6)
+    opt.step()
+    tr.optimizer_step()
+    sd = tr.state_dict()
+    grads_ref = {k: orc.w[k].grad.clone() for k in keys}
+    for k, p in zip(keys, params):
+        d = (sd[k].cpu() - p.detach()).abs()
+        # The first update is lr * g / (|g| + eps), eps = 1e-8: entries whose gradient is of eps' size or rounding
+        # noise move by anything up to lr in either implementation; the others must agree closely.
+        solid = grads_ref[k].abs() >= 1e-6
+        assert float(d.max()) <= 2.02e-4, (k, float(d.max()))             # +lr in one, -lr in the other at worst
+        if solid.any():
+            assert float(d[solid].max()) < 2e-7, (k, float(d[solid].max()))
+
+
+def test_config4_tsp10000_beam16_fast_path_at_size(device):
+    """Configuration 4 at its own size: one TSP instance of 10000 nodes, beam 16, through the device-resident beam
+    path (policy -> expansion over beam*k candidates -> linked step with the shared candidate compaction of long
+    rows).  60 decode steps against the oracle's dense rollout (10000 x 10000 matrix, top-k over 160000 entries):
+    back-pointers and chosen nodes of every step, beam scores, and the partial tours rebuilt by the backtrack."""
+    from dgl_amd._lib import PROBLEM_TSP
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from dgl_amd.weights import load_checkpoint
+    from conftest import GOLDEN
+    import os
+    from oracle.dgl_oracle import TSPOracle, beam_advance
+    Nn, beam, knn, steps = 10000, 16, 30, 60
+    xy = torch.rand(1, Nn, 2, generator=torch.Generator().manual_seed(4))
+    weights = load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt"))
+    orc = TSPOracle(weights, knn)
+    eng = TspEngine(xy.to(device), beam, knn)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    start = torch.full((beam,), 1234, dtype=torch.int64)
+    scores_ref = torch.zeros(1, beam)
+    scores = torch.zeros(1, beam, dtype=torch.float32, device=device)
+    prev_k = torch.zeros(1, beam, dtype=torch.int32, device=device)
+    action = torch.zeros(1, beam, dtype=torch.int32, device=device)
+    with torch.no_grad():
+        orc.reset(xy, rows_per_instance=beam, chain=True)
+        orc.step(start)
+        eng.reset()
+        eng.step(start.to(device=device, dtype=torch.int32))
+        for step in range(1, steps + 1):
+            out = orc.forward()
+            # (stable: equal scores go to the lower flat index, the tie-break this build fixes; with a trained
+            # checkpoint most of a row's candidates sit on the probability floor, so ties are the rule here and
+            # torch.topk over 160000 entries leaves their order to its selection algorithm)
+            scores_ref, pk_ref, act_ref = beam_advance(torch.log(out["probs"].view(1, beam, -1)), scores_ref, step, beam, Nn,
+                                                       stable=True)
+            orc.permute_beams(pk_ref, beam)
+            orc.step(act_ref.reshape(-1))
+            eng.forward(pol, want_logits=False, want_selected=False)
+            eng.beam_advance(scores, beam, step, prev_k, action)
+            eng.step_beam(prev_k.view(-1), action.view(-1), beam)
+            assert np.array_equal(action.cpu().numpy(), act_ref.numpy()), step
+            assert np.array_equal(prev_k.cpu().numpy(), pk_ref.numpy()), step
+            np.testing.assert_allclose(scores.cpu().numpy(), scores_ref.numpy(), rtol=2e-4, atol=2e-5)
+        eng.backtrack(2)
+    t = eng.t
+    assert t == steps + 1
+    assert np.array_equal(eng.state["tour"].cpu().numpy()[:, :t], orc.tour.numpy()[:, :t])
+    # the state the 16 rows carry after 60 linked steps: the oracle's, re-indexed by the same back-pointers
+    tol = (4e-7 + 3e-7 * np.sqrt(t)) * Nn / (Nn - t)          # (rounding drift of two float trajectories, see configuration 5)
+    np.testing.assert_allclose(eng.state["avg"].cpu().numpy(), orc.avg.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(eng.state["sd"].cpu().numpy(), orc.std.numpy(), rtol=tol, atol=tol)
