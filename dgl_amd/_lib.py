@@ -49,7 +49,8 @@ class PolicyIO(Structure):
                 ("idx_stride", c_int32), ("idx_dep_stride", c_int32), ("tile_row_stride", c_int32),
                 ("arithmetic", c_int32), ("out_stride", c_int32),
                 ("tile", c_void_p), ("idx_last", c_void_p), ("idx_depot", c_void_p), ("infeasible", c_void_p),
-                ("logits_out", c_void_p), ("prob_out", c_void_p), ("selected_out", c_void_p)]
+                ("logits_out", c_void_p), ("prob_out", c_void_p), ("selected_out", c_void_p),
+                ("overflow_out", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/dgl_amd.h declares

@@ -63,15 +63,27 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
     hi = pack_rtz(a, b);
     lo = pack_rtz(minus_half_lo(a, hi), minus_half_hi(b, hi));
 }
+// Range guard: the largest operand magnitude this lane has split, as binary32 bits of a non-negative float (one
+// v_max3_f32 with |.| source modifiers per pair of values).  65504 is where the round-towards-zero conversion to
+// binary16 saturates.
+#ifndef DGL_RANGE_GUARD
+#define DGL_RANGE_GUARD 1
+#endif
+__device__ __forceinline__ void track_range(float a, float b, float &mx) {
+#if DGL_RANGE_GUARD
+    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), __builtin_fabsf(b));
+#endif
+}
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // registers r0..r0+7 of an accumulator tile as one MFMA operand fragment (hi and lo)
-__device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8 &lo) {
+__device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8 &lo, float &mx) {
     u32x4 h, l;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         unsigned a, b;
         split2(x[r0 + 2 * p], x[r0 + 2 * p + 1], a, b);
+        track_range(x[r0 + 2 * p], x[r0 + 2 * p + 1], mx);
         h[p] = a;
         l[p] = b;
     }
@@ -81,7 +93,7 @@ __device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8
 
 // hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
 // of this lane's half): dst points at [token][feature base + 4h]
-__device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float16 *L) {
+__device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float16 *L, float &mx) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         u32x2 hi, lo;
@@ -89,6 +101,7 @@ __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float
         for (int p = 0; p < 2; ++p) {
             unsigned a, b;
             split2(x[4 * g + 2 * p], x[4 * g + 2 * p + 1], a, b);
+            track_range(x[4 * g + 2 * p], x[4 * g + 2 * p + 1], mx);
             hi[p] = a;
             lo[p] = b;
         }
@@ -213,6 +226,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
     unsigned long long st_[32];
     int nst = 0;
 #endif
+    float range_mx = 0.0f;                             // range guard: largest magnitude this lane has split (track_range)
     STAMP();
     for (int i = threadIdx.x; i < NVEC; i += 256 * GROUPS) vecs[i] = P[PK_VEC0 + i];
     WeightRing<PF16> ring;
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
             }
         }
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+        for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
     }
     __syncthreads();
     STAMP();
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
                             for (int e = 0; e < 4; ++e)
                                 xres[rr][4 * g + e] = (a == 0 ? a0[rr][4 * g + e] : a1[rr][4 * g + e]) + bb[e];
                         }
-                        store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+                        store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
                     }
                 }
             }
@@ -347,15 +361,16 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
             f32x16 o_sel = zero16();
+            float pmx = 0.0f;                                // (attention weights lie in [0, 1]: their range is not tracked)
             f16x8 vh[2], vl[2];                              // V[key][feature]: keys summed, two K-steps
-            split8(av[rr], 0, vh[0], vl[0]);
-            split8(av[rr], 8, vh[1], vl[1]);
+            split8(av[rr], 0, vh[0], vl[0], range_mx);
+            split8(av[rr], 8, vh[1], vl[1], range_mx);
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
                 // S^T[key j][query i] = sum_d K[j][d] Q[i][d]: the 16 d of this head are one K-step
                 f16x8 kh, kl, qh, ql;
-                split8(ak[rr], 8 * hd, kh, kl);
-                split8(aq[rr], 8 * hd, qh, ql);
+                split8(ak[rr], 8 * hd, kh, kl, range_mx);
+                split8(aq[rr], 8 * hd, qh, ql, range_mx);
                 f32x16 s = zero16();
                 s = MFMA16(kl, qh, s);
                 s = MFMA16(kh, ql, s);
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     f16x8 ph, pl;
-                    split8(s, 8 * t, ph, pl);
+                    split8(s, 8 * t, ph, pl, pmx);
                     o = MFMA16(vl[t], ph, o);
                     o = MFMA16(vh[t], pl, o);
                     o = MFMA16(vh[t], ph, o);
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
 #pragma unroll
                 for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m] * inv;
             }
-            store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr);
+            store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr, range_mx);
         }
         STAMP();   // attention done
         __syncthreads();
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
             }
             // every wave passed the barrier above after its Q/K/V reads of X: X may be replaced
 #pragma unroll
-            for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+            for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
         }
         STAMP();   // combine done
         __syncthreads();
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
                         for (int rr = 0; rr < ROWS; ++rr) ah[rr][4 * g + e] = fmaxf(ah[rr][4 * g + e] + bb[e], 0.0f);
                 }
 #pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr);
+                for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr, range_mx);
             };
             Unroll<0, 4>::run([&](auto hcc) {
                 constexpr int hc = decltype(hcc)::value;
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
                             v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
                         } else if constexpr (part == 1) {
                             hq[rr] = pack_rtz(v0[rr], v1[rr]);
+                            track_range(v0[rr], v1[rr], range_mx);
                             t0[rr] = minus_half_lo(v0[rr], hq[rr]);
                             t1[rr] = minus_half_hi(v1[rr], hq[rr]);
                         } else {
@@ -504,13 +520,16 @@ __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *_
             // the last barrier came after every wave's last read of X (W1 of chunk 3)
             if (layer < 3) {
 #pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr);
+                for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
             }
         }
         STAMP();   // FF done
         __syncthreads();
         STAMP();   // barrier
     }
+    // an operand reached the binary16 range somewhere in this row's network: tell the host (it repeats the work with
+    // the binary32 kernel); every writer stores the same value
+    if (io.overflow_out != nullptr && !(range_mx < 65504.0f)) *io.overflow_out = 1;
 #ifdef PROFILE_STAMPS
     if (tid == 0 && io.logits_out)
         for (int i = 0; i < 32; ++i) io.logits_out[(size_t)row0 * DGL_MAX_TOKENS + i] = i < nst ? (float)(st_[i] - st_[0]) : 0.f;

@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import PROBLEM_CVRP, check, ptr, stream_ptr
 from .augment import mix_augment
-from .engine import CvrpEngine, PackedPolicy
+from .engine import CvrpEngine, PackedPolicy, forward_range_guarded
 from .formats import read_cvrp_instances_from_file
 from .nn_layout import DecoderParams, EncoderParams
 
@@ -308,5 +308,5 @@ class CVRPModel(nn.Module):
             is_via_depot = solution_flag[:, current_step] == 1
             selected_teacher[is_via_depot] += eng.N + 1
             return selected_teacher, teacher_probability(self, eng, PROBLEM_CVRP, selected_teacher), 1
-        eng.forward(self.packed(eng.device))
+        forward_range_guarded(eng, self.packed(eng.device))
         return None, eng.dense_probs(), 1

@@ -109,6 +109,39 @@ def policy_forward(engine, policy: PackedPolicy, io: _lib.PolicyIO) -> None:
                                             stream_ptr()), "dgl_policy_general")
 
 
+def range_guarded(rollout):
+    """Rollout methods under the split-f16 arithmetic: if the kernel reported an operand at the edge of the binary16
+    range (|v| >= 65504; a network without LayerNorm does not bound its activations), the whole rollout is repeated
+    with the binary32 kernel.  One 4-byte read per rollout."""
+    @functools.wraps(rollout)
+    def wrapper(self, *args, **kw):
+        self.overflow.zero_()
+        out = rollout(self, *args, **kw)
+        self.reran_f32 = False
+        if self.arithmetic == _lib.ARITH_SPLIT_F16 and int(self.overflow.item()) != 0:
+            self.arithmetic = _lib.ARITH_F32
+            try:
+                out = rollout(self, *args, **kw)
+            finally:
+                self.arithmetic = _lib.ARITH_SPLIT_F16
+            self.reran_f32 = True
+        return out
+    return wrapper
+
+
+def forward_range_guarded(engine, policy: "PackedPolicy") -> None:
+    """One policy evaluation for the reference-protocol path (model.forward): repeated with the binary32 kernel
+    when the split-f16 kernel reports an operand at the edge of the binary16 range."""
+    engine.overflow.zero_()
+    engine.forward(policy)
+    if engine.arithmetic == _lib.ARITH_SPLIT_F16 and engine.out_w == MAX_TOKENS and int(engine.overflow.item()) != 0:
+        engine.arithmetic = _lib.ARITH_F32
+        try:
+            engine.forward(policy)
+        finally:
+            engine.arithmetic = _lib.ARITH_SPLIT_F16
+
+
 class TspEngine:
     """Compact TSP state for R = B * rows_per_instance rows plus per-step scratch."""
 
@@ -132,6 +165,7 @@ class TspEngine:
         self._alloc_outputs()
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)      # set by the split-f16 kernel (range guard)
         self.t = 0
         self.tile_t = -1                 # step count the neighbourhood buffers (idx, tile) belong to
         self._beam_bufs = None
@@ -206,7 +240,7 @@ class TspEngine:
         return _lib.PolicyIO(PROBLEM_TSP, self.R, k + 1, k, self.N, self.knn, 0, (self.knn + 1) * TILE_STRIDE,
                              self.arithmetic, self.out_stride, ptr(self.tile), ptr(self.idx), 0, 0,
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
-                             ptr(self.selected) if want_selected else 0)
+                             ptr(self.selected) if want_selected else 0, ptr(self.overflow))
 
     @on_own_device
     def forward(self, policy: PackedPolicy, **kw) -> None:
@@ -251,6 +285,7 @@ class TspEngine:
         return self.length
 
     @on_own_device
+    @range_guarded
     def greedy_rollout(self, policy: PackedPolicy, start: torch.Tensor) -> torch.Tensor:
         """Whole greedy decode (beam 1): N-1 policy decisions, everything stays on the device."""
         self.reset()
@@ -294,6 +329,7 @@ class TspEngine:
               "dgl_tsp_beam_backtrack")
 
     @on_own_device
+    @range_guarded
     def beam_rollout(self, policy: PackedPolicy, start: torch.Tensor, beam: int) -> torch.Tensor:
         """Beam-search decode (TSP/TSPTester.py:145-199) on the compact state: per step the policy, the beam
         expansion over beam*k candidates and one pass over the state that follows the back-pointers while it
@@ -351,6 +387,7 @@ class CvrpEngine:
         self._alloc_outputs()
         self.selected = torch.zeros(R, dtype=torch.int32, device=dev)
         self.length = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)      # set by the split-f16 kernel (range guard)
         self.t = 0
         self.tile_t = -1
 
@@ -435,7 +472,7 @@ class CvrpEngine:
                              self.ntok_max * TILE_STRIDE, self.arithmetic, self.out_stride, ptr(self.tile), ptr(self.idx_last), ptr(self.idx_dep),
                              ptr(self.infeasible),
                              ptr(self.logits) if want_logits else 0, ptr(self.prob) if want_prob else 0,
-                             ptr(self.selected) if want_selected else 0)
+                             ptr(self.selected) if want_selected else 0, ptr(self.overflow))
 
     @on_own_device
     def forward(self, policy: PackedPolicy, **kw) -> None:
@@ -485,6 +522,7 @@ class CvrpEngine:
     tour_length = route_length
 
     @on_own_device
+    @range_guarded
     def greedy_rollout(self, policy: PackedPolicy, start_action: torch.Tensor) -> torch.Tensor:
         self.reset()
         self.step(start_action)
@@ -527,6 +565,7 @@ class CvrpEngine:
               "dgl_cvrp_beam_backtrack")
 
     @on_own_device
+    @range_guarded
     def beam_rollout(self, policy: PackedPolicy, start_action: torch.Tensor, beam: int) -> torch.Tensor:
         """Beam-search decode (CVRP/CVRPTester.py:147-227) on the compact state; the step follows the
         back-pointers while it updates, nodes and flags are rebuilt from the history at the end."""

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import PROBLEM_TSP, check, ptr, stream_ptr
 from .augment import mix_augment
-from .engine import PackedPolicy, TspEngine
+from .engine import PackedPolicy, TspEngine, forward_range_guarded
 from .formats import read_baseline_lengths, read_tsp_instances
 from .nn_layout import DecoderParams, EncoderParams
 
@@ -233,5 +233,5 @@ class TSPModel(nn.Module):
             from .train import teacher_probability
             selected_teacher = solution[:, current_step]
             return selected_teacher, teacher_probability(self, eng, PROBLEM_TSP, selected_teacher), 1
-        eng.forward(self.packed(eng.device))
+        forward_range_guarded(eng, self.packed(eng.device))
         return None, eng.dense_probs(), 1

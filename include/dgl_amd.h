@@ -222,7 +222,7 @@ DGL_API int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl_st
  *  DGL_ARITH_SPLIT_F16: every operand is split into hi = binary16(x), lo = binary16(x - hi) and the
  *    product is evaluated as hi*hi + hi*lo + lo*hi on the binary16 matrix cores with binary32
  *    accumulation (22 significant bits per operand; measured error no larger than a binary32 FMA
- *    chain of the same length).  Operands beyond +-65504 saturate.
+ *    chain of the same length).  Operands beyond +-65504 saturate: io->overflow_out reports it.
  *  DGL_ARITH_F32: binary32-input matrix instructions, bitwise equal to FMA chains. */
 #define DGL_ARITH_SPLIT_F16 0
 #define DGL_ARITH_F32 1
@@ -245,6 +245,9 @@ typedef struct {
     float *logits_out;
     float *prob_out;
     int32_t *selected_out;
+    int32_t *overflow_out;      /* may be NULL.  DGL_ARITH_SPLIT_F16 stores 1 here when some operand of a dense contraction
+                                   reached the binary16 range (|v| >= 65504: the result is then unreliable and the caller
+                                   repeats the call with DGL_ARITH_F32); never cleared by the library */
 } dgl_policy_io_t;
 
 /* Runs the network described above for every row (TSP/TSPModel.py:174-231,

@@ -94,3 +94,36 @@ def test_f32_kernel_logits_match_golden(name, device):
             worst = max(worst, float((np.abs(lg[ok] - g[ok]) / np.abs(g[ok]).max(axis=1, keepdims=True)).max()))
     print(f"{name}: f32 kernel max relative logit error {worst:.2e}")
     assert worst < 1e-3
+
+
+def test_range_guard_reruns_in_binary32(device):
+    """Weights scaled so that activations leave the binary16 range: the split-f16 kernel reports it
+    (dgl_policy_io_t.overflow_out) and the rollout is repeated with the binary32 kernel, so the result is the
+    binary32 kernel's; with ordinary weights nothing is reported."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from oracle.dgl_oracle import random_weights
+    g = torch.Generator().manual_seed(3)
+    xy = torch.rand(8, 60, 2, generator=g).to(device)
+    start = torch.zeros(8, dtype=torch.int32, device=device)
+    w = random_weights("TSP", 5)
+    big = dict(w)
+    big["encoder.embedding.weight"] = w["encoder.embedding.weight"] * 3e5      # tokens are O(1): activations ~1e5
+    eng = TspEngine(xy, 1, 30)
+    assert eng.arithmetic == _lib.ARITH_SPLIT_F16
+    eng.greedy_rollout(PackedPolicy(w, _lib.PROBLEM_TSP, device), start)
+    assert eng.reran_f32 is False and int(eng.overflow.item()) == 0
+    eng.greedy_rollout(PackedPolicy(big, _lib.PROBLEM_TSP, device), start)
+    assert eng.reran_f32 is True
+    tour = eng.state["tour"].clone()
+    ref = TspEngine(xy, 1, 30)
+    ref.arithmetic = _lib.ARITH_F32
+    ref.greedy_rollout(PackedPolicy(big, _lib.PROBLEM_TSP, device), start)
+    assert ref.reran_f32 is False and torch.equal(ref.state["tour"], tour)
+    # the reference-protocol path checks per evaluation
+    from dgl_amd.engine import forward_range_guarded
+    eng.reset(); eng.step(start)
+    forward_range_guarded(eng, PackedPolicy(big, _lib.PROBLEM_TSP, device))
+    sel = eng.selected.clone()
+    ref.reset(); ref.step(start); ref.forward(PackedPolicy(big, _lib.PROBLEM_TSP, device))
+    assert torch.equal(sel, ref.selected)
