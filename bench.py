@@ -3,8 +3,10 @@
 
 A *step* is one full greedy decode of one batch of synthetic instances (reset, N-1 policy
 decisions with the fused state-update/kNN/tile kernel in between, tour length): one pass
-of the hot path over one batch.  Default workload: TSP-1000, 512 uniform instances per GPU,
-k = 30 (BASELINE.json configs[1]); ``--problem cvrp`` runs CVRP-1000 (configs[2]).
+of the hot path over one batch.  Headline workload: TSP-1000, 512 uniform instances per GPU,
+k = 30 (BASELINE.json configs[1]); by default CVRP-1000 (configs[2]'s workload, k = kd = 15) is
+run after it with the same step / warm-up counts and reported under the key ``cvrp1000`` of the
+same JSON line (``--problem tsp`` / ``--problem cvrp`` run one of them alone).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -12,12 +14,16 @@ k = 30 (BASELINE.json configs[1]); ``--problem cvrp`` runs CVRP-1000 (configs[2]
 Rank 0 prints ONE JSON line.  ``value`` is whole-job instances/s (all ranks; instances are
 independent, so ranks shard them with no data-path collective: weak scaling); only the
 tour-length statistics are all-reduced (RCCL) at the end.  ``roofline`` describes the
-dominant kernel (the policy network; its dense contractions run on the f16 matrix cores with
-split operands, three f16 products per f32-accurate product, so the peak it is priced against is
-the dense f16 peak / 3), timed with HIP events on the launch stream inside the timed region;
-``policy_f32_kernel`` times the selectable f32-input-MFMA kernel on the same tiles; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
-the workload's batch and at a batch large enough to fill the chip.  ``cpu_baseline`` is the
-oracle (the PyTorch-CPU restatement of the reference path) on a bounded sample.
+dominant kernel (the policy network), timed with HIP events on the launch stream inside the
+timed region: ``achieved`` = algorithmic flops per launch / average launch time, ``frac`` = that
+over the nominal dense f16 matrix peak.  (The kernel reaches binary32 accuracy by evaluating
+every product as three f16 products; ``frac_of_executed_f16_work`` = 3 x frac is the matrix-core
+utilisation of the executed work.)  ``policy_f32_kernel`` times the selectable f32-input-MFMA
+kernel on the same tiles; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
+the workload's batch and at a batch large enough to fill the chip; ``measured_peaks`` what this
+card delivers for a float4 triad / copy and for back-to-back matrix instructions on random
+operands.  ``cpu_baseline`` is the oracle (the PyTorch-CPU restatement of the reference path) on a
+bounded sample.
 """
 from __future__ import annotations
 
@@ -53,64 +59,88 @@ def knn_bytes_per_row(nodes: int, k: int, cvrp: bool) -> float:
     return 24 * nodes + nodes / 8 + 8 * k
 
 
-def pmc_traffic(args, B, knn, kernel):
+KERNEL_SOURCES = ["policy16.hip", "policy.hip", "policy_layout.h", "tsp_state.hip", "cvrp_state.hip", "select.h",
+                  "state_common.h", "common.h"]
+
+
+def kernel_source_hash() -> str:
+    """Hash of the sources of the kernels whose counter traffic profiles/pmc_traffic.json records."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "dgl_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(problem, N, B, knn, kernel):
     """HBM-side bytes per launch of ``kernel`` from the committed counter pass of this workload (the counters
-    cannot be read from inside the process); None when no pass was recorded for it."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    cannot be read from inside the process).  None when no pass was recorded for it, or when the kernels' sources
+    have changed since the pass was recorded (the record carries their hash)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
     except OSError:
         return None
-    entry = rec.get(f"{args.problem}{args.nodes}_b{B}_k{knn}", {}).get(kernel)
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    entry = rec.get(f"{problem}{N}_b{B}_k{knn}", {}).get(kernel)
     return entry["bytes_per_launch"] if entry else None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--problem", choices=["tsp", "cvrp"], default="tsp")
-    ap.add_argument("--nodes", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=512, help="instances per GPU")
-    ap.add_argument("--knn", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="instances decoded by the CPU baseline")
-    ap.add_argument("--no-aux", action="store_true", help="skip the saturating-batch kNN measurement")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-            sys.exit(2)
-    # one rank per GPU; DGL_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on one card
-    backend = os.environ.get("DGL_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+def measured_peaks(dev):
+    """What this card delivers: streaming kernels over 1 GiB arrays and back-to-back matrix instructions on random
+    operands (dgl_amd/csrc/bench_peaks.hip), quoted beside the nominal figures."""
+    import ctypes
     from dgl_amd import build
-    if local_rank == 0:
-        build.build()                               # no-op when the in-tree library is current
-    if dist is not None:
-        dist.barrier()                              # the other ranks load the library only after that
+    lib = ctypes.CDLL(build.build_peaks())
+    vp, f, i64, i32 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int64, ctypes.c_int32
+    lib.dglb_triad.argtypes = [vp, vp, vp, f, i64, i32, i32, vp]
+    lib.dglb_copy.argtypes = [vp, vp, i64, i32, i32, vp]
+    lib.dglb_mfma_f16.argtypes = [i32, i32, vp, vp]
+    lib.dglb_mfma_f32.argtypes = [i32, i32, vp, vp]
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << 28                                               # 1 GiB per array: far beyond the 256 MiB Infinity Cache
+    a, b, c = (torch.rand(n, device=dev) for _ in range(3))
+    sink = torch.zeros(4, device=dev)
+
+    def timed(fn, reps):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    # the best of {1, 4 float4 per thread} x {plain, non-temporal} accesses
+    variants = [(u, nt) for u in (1, 4) for nt in (0, 1)]
+    t_triad = min(timed(lambda: lib.dglb_triad(a.data_ptr(), b.data_ptr(), c.data_ptr(), 1.5, n, u, nt, st), 8) for u, nt in variants)
+    t_copy = min(timed(lambda: lib.dglb_copy(a.data_ptr(), b.data_ptr(), n, u, nt, st), 8) for u, nt in variants)
+    del a, b, c
+    blocks, it16, it32 = 2048, 4000, 1000
+    # ~0.5 s of back-to-back launches on random operands first: the clock the chip settles on under this load
+    t16 = timed(lambda: lib.dglb_mfma_f16(blocks, it16, sink.data_ptr(), st), 60)
+    t32 = timed(lambda: lib.dglb_mfma_f32(blocks, it32, sink.data_ptr(), st), 20)
+    fl16 = blocks * 4 * it16 * 4 * 2.0 * 32 * 32 * 16
+    fl32 = blocks * 4 * it32 * 4 * 2.0 * 32 * 32 * 2
+    return {"hbm_triad_GBs": 3 * 4 * n / t_triad / 1e9, "hbm_copy_GBs": 2 * 4 * n / t_copy / 1e9,
+            "mfma_f16_32x32x16_TFLOPs": fl16 / t16 / 1e12, "mfma_f32_32x32x2_TFLOPs": fl32 / t32 / 1e12,
+            "nominal": {"hbm_GBs": PEAK_HBM_GBS, "mfma_f16_TFLOPs": PEAK_F16_MATRIX_TFLOPS,
+                        "mfma_f32_TFLOPs": PEAK_FP32_MATRIX_TFLOPS},
+            "note": "float4 triad / copy over 1 GiB arrays; register-resident matrix instructions on random operands, "
+                    "8+ waves per SIMD-second of warm-up; roofline fractions are quoted against the NOMINAL peaks"}
+
+
+def run_problem(problem, args, world, rank, dev, dist):
+    """Times args.steps greedy rollouts of one problem on this rank's batch; returns this rank's result fields
+    (rank 0 gets the kernel-level fields)."""
     from dgl_amd._lib import ARITH_F32, ARITH_SPLIT_F16, PROBLEM_CVRP, PROBLEM_TSP
     from dgl_amd.engine import CvrpEngine, PackedPolicy, TspEngine
     from dgl_amd.weights import random_state_dict
 
-    cvrp = args.problem == "cvrp"
+    cvrp = problem == "cvrp"
     N, B = args.nodes, args.batch
     knn = args.knn or (15 if cvrp else 30)
     gen = torch.Generator().manual_seed(789 + rank)
@@ -136,6 +166,7 @@ def main():
     ev_policy, ev_knn, ev_null = [], [], []
 
     def rollout(sample: bool):
+        eng.overflow.zero_()
         eng.reset()
         eng.step(start)
         s = 0
@@ -173,6 +204,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the range guard of the split-f16 arithmetic, read once per run (random-init weights stay far inside the range)
+    assert int(eng.overflow.item()) == 0, "an activation left the binary16 range: rerun with DGL_ARITHMETIC=f32"
 
     stats = torch.tensor([float(length.double().sum()), float(B), elapsed], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -181,68 +214,133 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0])
     mean_len = float(stats[0] / stats[1])
+    if rank != 0:
+        return None
 
+    ms_null = sum(a.elapsed_time(b) for a, b in ev_null) / max(1, len(ev_null))
+    raw_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
+    raw_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
+    ms_policy, ms_knn = raw_policy - ms_null, raw_knn - ms_null
+    flops = policy_flops_per_row(n_tok, feat, anchors) * B
+    split = eng.arithmetic == ARITH_SPLIT_F16
+    peak_tf = PEAK_F16_MATRIX_TFLOPS if split else PEAK_FP32_MATRIX_TFLOPS
+    ach_tf = flops / (ms_policy * 1e-3) / 1e12 if ms_policy > 0 else 0.0
+    bytes_knn = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * B
+    ach_gbs = bytes_knn / (ms_knn * 1e-3) / 1e9 if ms_knn > 0 else 0.0
+    kname = "policy_kernel_f16" if split else "policy_kernel_f32"
+    out = {
+        "metric": f"instances/sec, {problem.upper()}-{N} greedy decode (node selection)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "instances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (f16 split-operand MFMA x3, f32 accumulate)" if split else "f32", "data": "synthetic",
+        "config": {"workload": f"{problem.upper()}-{N} greedy decode, {B} uniform instances per GPU, "
+                               f"k={knn}" + (f"/{knn}" if cvrp else "") + ", random-init weights",
+                   "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}"},
+        "decode_steps_per_s": args.steps * decisions / elapsed,
+        "row_decisions_per_s": world * B * args.steps * decisions / elapsed,
+        "mean_tour_length": mean_len,
+        "roofline": {"kernel": kname, "bound": "mfma",
+                     "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
+                     "traffic": pmc_traffic(problem, N, B, knn, kname),
+                     "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC pass recorded in profiles/pmc_traffic.json "
+                                     "(null when the kernel sources changed since)",
+                     "avg_launch_ms": ms_policy, "flops_per_launch": flops,
+                     "samples": len(ev_policy), "event_interval_ms": raw_policy, "empty_event_interval_ms": ms_null,
+                     "peak_note": ("nominal dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (one per f32-accurate "
+                                   f"multiply-add), the kernel executes {SPLIT_PASSES} f16 products for each: "
+                                   "frac_of_executed_f16_work is the matrix-core utilisation of the executed work"
+                                   if split else "nominal dense f32-input MFMA peak"),
+                     "frac_of_executed_f16_work": (SPLIT_PASSES * ach_tf / PEAK_F16_MATRIX_TFLOPS) if split else None},
+        "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
+                         "traffic": pmc_traffic(problem, N, B, knn, "step_kernel"),
+                         "avg_launch_ms": ms_knn, "event_interval_ms": raw_knn, "bytes_per_launch": bytes_knn, "rows": B},
+    }
+    if cvrp:
+        out["roofline_knn"]["bytes_note"] = ("per-row figure 28 m + m/4 + 8 (k + kd) with a demand read per node; the "
+                                             "kernel reads the candidates' demand only, about 24 m bytes move")
+    if not args.no_aux and world == 1:
+        out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, problem, N, knn)
+        if split and not cvrp:                   # the f32-input kernel on tiles of the same shape, outside the timed region
+            eng.reset(); eng.step(start)
+            eng.arithmetic = ARITH_F32
+            for _ in range(3):
+                eng.forward(policy, want_logits=False, want_prob=False)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                eng.forward(policy, want_logits=False, want_prob=False)
+            b.record(); torch.cuda.synchronize()
+            eng.arithmetic = ARITH_SPLIT_F16
+            ms32 = a.elapsed_time(b) / 10
+            out["policy_f32_kernel"] = {"kernel": "policy_kernel_f32", "avg_launch_ms": ms32,
+                                        "achieved": flops / (ms32 * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(problem, N, knn, args.cpu_sample)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--problem", choices=["both", "tsp", "cvrp"], default="both",
+                    help="both: TSP is the headline line, CVRP's results ride along under the key cvrp<nodes>")
+    ap.add_argument("--nodes", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=512, help="instances per GPU")
+    ap.add_argument("--knn", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="instances decoded by the CPU baseline")
+    ap.add_argument("--no-aux", action="store_true", help="skip the saturating-batch kNN and measured-peak measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    # one rank per GPU; DGL_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on one card
+    backend = os.environ.get("DGL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    from dgl_amd import build
+    if local_rank == 0:
+        build.build()                               # no-op when the in-tree library is current
+    if dist is not None:
+        dist.barrier()                              # the other ranks load the library only after that
+
+    first = "cvrp" if args.problem == "cvrp" else "tsp"
+    out = run_problem(first, args, world, rank, dev, dist)
+    other = run_problem("cvrp", args, world, rank, dev, dist) if args.problem == "both" else None
     if rank == 0:
-        ms_null = sum(a.elapsed_time(b) for a, b in ev_null) / max(1, len(ev_null))
-        raw_policy = sum(a.elapsed_time(b) for a, b in ev_policy) / max(1, len(ev_policy))
-        raw_knn = sum(a.elapsed_time(b) for a, b in ev_knn) / max(1, len(ev_knn))
-        ms_policy, ms_knn = raw_policy - ms_null, raw_knn - ms_null
-        flops = policy_flops_per_row(n_tok, feat, anchors) * B
-        split = eng.arithmetic == ARITH_SPLIT_F16
-        peak_tf = PEAK_F16_MATRIX_TFLOPS / SPLIT_PASSES if split else PEAK_FP32_MATRIX_TFLOPS
-        ach_tf = flops / (ms_policy * 1e-3) / 1e12 if ms_policy > 0 else 0.0
-        bytes_knn = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * B
-        ach_gbs = bytes_knn / (ms_knn * 1e-3) / 1e9 if ms_knn > 0 else 0.0
-        out = {
-            "metric": f"instances/sec, {args.problem.upper()}-{N} greedy decode (node selection)",
-            "value": world * B * args.steps / elapsed,
-            "unit": "instances/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (f16 split-operand MFMA x3, f32 accumulate)" if split else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.problem.upper()}-{N} greedy decode, {B} uniform instances per GPU, "
-                                   f"k={knn}" + (f"/{knn}" if cvrp else "") + ", random-init weights",
-                       "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}"},
-            "decode_steps_per_s": args.steps * decisions / elapsed,
-            "row_decisions_per_s": world * B * args.steps * decisions / elapsed,
-            "mean_tour_length": mean_len,
-            "roofline": {"kernel": "policy_kernel_f16" if split else "policy_kernel_f32", "bound": "mfma",
-                         "achieved": ach_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf,
-                         "traffic": pmc_traffic(args, B, knn, "policy_kernel_f16" if split else "policy_kernel_f32"),
-                         "traffic_unit": "HBM-side bytes per launch, rocprofv3 PMC pass recorded in profiles/pmc_traffic.json",
-                         "avg_launch_ms": ms_policy, "flops_per_launch": flops,
-                         "samples": len(ev_policy), "event_interval_ms": raw_policy, "empty_event_interval_ms": ms_null,
-                         "peak_note": (f"dense f16 MFMA peak {PEAK_F16_MATRIX_TFLOPS} / {SPLIT_PASSES} passes per "
-                                       "f32-accurate product" if split else "dense f32-input MFMA peak"),
-                         "frac_of_f16_dense_peak": ach_tf / PEAK_F16_MATRIX_TFLOPS},
-            "roofline_knn": {"kernel": "step_kernel", "bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS,
-                             "traffic": pmc_traffic(args, B, knn, "step_kernel"),
-                             "avg_launch_ms": ms_knn, "event_interval_ms": raw_knn, "bytes_per_launch": bytes_knn, "rows": B},
-        }
-        if cvrp:
-            out["roofline_knn"]["bytes_note"] = ("per-row figure 28 m + m/4 + 8 (k + kd) with a demand read per node; the "
-                                                 "kernel reads the candidates' demand only, about 24 m bytes move")
+        if other is not None:
+            out[f"cvrp{args.nodes}"] = {k: other[k] for k in ("metric", "value", "unit", "ms_per_step", "config",
+                                                              "decode_steps_per_s", "mean_tour_length", "roofline",
+                                                              "roofline_knn", "cpu_baseline") if k in other}
         if not args.no_aux and world == 1:
-            out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, args.problem, N, knn)
-            if split:                                # the f32-input kernel on tiles of the same shape, outside the timed region
-                eng.reset(); eng.step(start)
-                eng.arithmetic = ARITH_F32
-                for _ in range(3):
-                    eng.forward(policy, want_logits=False, want_prob=False)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _ in range(10):
-                    eng.forward(policy, want_logits=False, want_prob=False)
-                b.record(); torch.cuda.synchronize()
-                eng.arithmetic = ARITH_SPLIT_F16
-                ms32 = a.elapsed_time(b) / 10
-                out["policy_f32_kernel"] = {"kernel": "policy_kernel_f32", "avg_launch_ms": ms32,
-                                            "achieved": flops / (ms32 * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                                            "unit": "TFLOP/s", "frac": flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.problem, N, knn, args.cpu_sample)
+            out["measured_peaks"] = mp = measured_peaks(dev)
+            for o in (out, out.get(f"cvrp{args.nodes}")):
+                if o:
+                    o["roofline"]["frac_of_measured_f16_peak"] = o["roofline"]["achieved"] / mp["mfma_f16_32x32x16_TFLOPs"]
+                    o["roofline_knn"]["frac_of_measured_copy_rate"] = o["roofline_knn"]["achieved"] / mp["hbm_copy_GBs"]
+        out["kernel_source_hash"] = kernel_source_hash()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
