@@ -80,6 +80,7 @@ SIGNATURES = {
     "dgl_policy_packed_floats": (c_int64, [c_int32]),
     "dgl_policy_pack": (c_int32, [POINTER(PolicyWeights), c_void_p, c_void_p]),
     "dgl_policy_forward": (c_int32, [c_void_p, POINTER(PolicyIO), c_void_p]),
+    "dgl_tsp_greedy_decode": (c_int32, [POINTER(TspState), c_void_p, POINTER(PolicyIO), c_int32, c_int32, c_int32, c_void_p]),
     "dgl_policy_general_workspace_floats": (c_int64, [c_int32, c_int32]),
     "dgl_policy_general": (c_int32, [POINTER(PolicyWeights), POINTER(PolicyWeights), POINTER(PolicyIO), c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,569 @@
+// Body of the split-f16 policy kernel (see policy16.hip for the description): a device function, so that the same
+// code runs as a kernel of its own (policy16.hip) and inside the fused decode kernel (rollout.hip).
+#pragma once
+#include "policy_layout.h"
+
+#define LDH 136                               // LDS row stride in halfs
+#define ARR (32 * LDH)                        // halfs per [32 tokens][128 features] image
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+#define NHEAD PK_STREAM0                         // embedding + bias vectors + final weights: staged in LDS (multiple of 4)
+
+// Split of activations: hi = binary16(v) rounded towards zero (one packed conversion for two values),
+// lo = binary16(v - hi), the difference formed exactly by one mixed-precision FMA that reads hi
+// straight from the packed register: four VALU operations per pair, 22 significant bits kept.
+// Magnitudes above 65504 saturate in hi and continue in lo; below 2^-14 the absolute accuracy is 2^-24.
+__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// a - (low / high half of hh, read as binary16), exact in binary32
+__device__ __forceinline__ float minus_half_lo(float a, unsigned hh) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float minus_half_hi(float a, unsigned hh) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = pack_rtz(a, b);
+    lo = pack_rtz(minus_half_lo(a, hi), minus_half_hi(b, hi));
+}
+// Range guard: the largest operand magnitude this lane has split, as binary32 bits of a non-negative float (one
+// v_max3_f32 with |.| source modifiers per pair of values).  65504 is where the round-towards-zero conversion to
+// binary16 saturates.
+#ifndef DGL_RANGE_GUARD
+#define DGL_RANGE_GUARD 1
+#endif
+__device__ __forceinline__ void track_range(float a, float b, float &mx) {
+#if DGL_RANGE_GUARD
+    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), __builtin_fabsf(b));
+#endif
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// registers r0..r0+7 of an accumulator tile as one MFMA operand fragment (hi and lo)
+__device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8 &lo, float &mx) {
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned a, b;
+        split2(x[r0 + 2 * p], x[r0 + 2 * p + 1], a, b);
+        track_range(x[r0 + 2 * p], x[r0 + 2 * p + 1], mx);
+        h[p] = a;
+        l[p] = b;
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
+// hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
+// of this lane's half): dst points at [token][feature base + 4h]
+__device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float16 *L, float &mx) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u32x2 hi, lo;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            unsigned a, b;
+            split2(x[4 * g + 2 * p], x[4 * g + 2 * p + 1], a, b);
+            track_range(x[4 * g + 2 * p], x[4 * g + 2 * p + 1], mx);
+            hi[p] = a;
+            lo[p] = b;
+        }
+        *reinterpret_cast<u32x2 *>(H + 8 * g) = hi;
+        *reinterpret_cast<u32x2 *>(L + 8 * g) = lo;
+    }
+}
+
+// acc[rr] += W(out tile) * X[rr]^T over K = 128 (8 steps of 16): transposed product, lane = token.
+// H, L: this lane's operand pointer into the hi / lo image of row 0 ([token q][8h]); rows ARRS apart.
+// BASE: position of the GEMM's first fragment in the wave's stream, modulo the ring depth.
+template <int ROWS, int ARRS, int BASE>
+__device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
+                                         f32x16 (&acc)[ROWS]) {
+    // activation operands are read one K-step ahead of the MFMAs that consume them
+    f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS);
+        nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS);
+    }
+    Unroll<0, 8>::run([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
+        const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
+        f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+        if constexpr (s + 1 < 8) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS + 16 * (s + 1));
+                nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS + 16 * (s + 1));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads ahead of this step's MFMAs
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+            acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
+            acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+        }
+    });
+}
+
+// The same GEMM with independent VALU / LDS-store work placed in the shadow of its MFMAs: one wave
+// per SIMD issues in order, an MFMA occupies the issue port for 8 of its 32 cycles, so up to five
+// 4-cycle VALU instructions written between two MFMAs cost nothing.  side(step, row, part) is called
+// after MFMA `part` (0..2) of `row` in K-step `step` and must not depend on acc; scheduling barriers
+// pin the written order.
+template <int ROWS, int ARRS, int BASE, class Side>
+__device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
+                                              f32x16 (&acc)[ROWS], Side side) {
+    f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS);
+        nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS);
+    }
+    Unroll<0, 8>::run([&](auto ss) {
+        constexpr int s = decltype(ss)::value;
+        const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
+        const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
+        f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+        if constexpr (s + 1 < 8) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(H + rr * ARRS + 16 * (s + 1));
+                nl[rr] = *reinterpret_cast<const f16x8 *>(L + rr * ARRS + 16 * (s + 1));
+            }
+        }
+        Unroll<0, 3>::run([&](auto pp) {
+            constexpr int part = decltype(pp)::value;
+            Unroll<0, ROWS>::run([&](auto rc) {
+                constexpr int rr = decltype(rc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (part == 0) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+                if constexpr (part == 1) acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
+                if constexpr (part == 2) acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+                __builtin_amdgcn_sched_barrier(0);
+                side(ss, rc, pp);
+            });
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifdef PROFILE_STAMPS
+#define STAMP() do { if (tid == 0 && nst < 32) st_[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+
+// The network for the rows of one workgroup: rows (wg * GROUPS + grp) * ROWS ...  `lds`: the workgroup's dynamic LDS
+// (policy16_lds_bytes<ROWS, GROUPS>()); called by all 256 * GROUPS threads (it contains workgroup barriers).
+// GROUPS = 2: a workgroup of 8 waves, two per SIMD.  Waves w and w + 4 own the same output features (the same
+// weight fragments) and work on different rows; they run the same program between the same barriers.  (Measured:
+// no faster than GROUPS = 1 with two rows per wave - the two waves of a SIMD do not speed each other's VALU phases
+// up, and the weight stream through the vector L1 doubles.  Kept for experiments, DGL_POLICY_SHAPE=21.)
+template <int ROWS, int GROUPS>
+__device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const dgl_policy_io_t &io, float *lds, int wg) {
+    constexpr int ROWH = 6 * ARR;                                   // halfs per row: XH XL BH BL CH CL
+    const int grp = GROUPS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    _Float16 *base = reinterpret_cast<_Float16 *>(lds) + grp * ROWS * ROWH;
+    float *part = lds + GROUPS * ROWS * ROWH / 2 + grp * 4 * ROWS * 32;   // [GROUPS][4][ROWS][32]
+    float *headv = lds + GROUPS * ROWS * ROWH / 2 + GROUPS * 4 * ROWS * 32;  // [NHEAD] copy of P[0 .. PK_STREAM0)
+    float *vecs = headv + PK_VEC0;                                           // the bias vectors and final weights in it
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int row0 = (wg * GROUPS + grp) * ROWS;
+    const int n = io.n;
+    // image pointers of row 0 (rows ROWH apart)
+    _Float16 *XH = base, *XL = base + ARR, *BH = base + 2 * ARR, *BL = base + 3 * ARR, *CH = base + 4 * ARR,
+             *CL = base + 5 * ARR;
+    // this lane's view of a 128-float vector: registers 4g..4g+3 <-> vl[off + 8g .. 8g+3]
+    const float *vl = vecs + 32 * w + 4 * h;
+    auto vec4 = [&](int off, int g) { return *reinterpret_cast<const f32x4 *>(vl + off + 8 * g); };
+    const int rd = q * LDH + 8 * h;                // operand read offset: [token q][8h]
+    const int wr = q * LDH + 32 * w + 4 * h;       // split store offset: [token q][32w + 4h]
+
+#ifdef PROFILE_STAMPS
+    unsigned long long st_[32];
+    int nst = 0;
+#endif
+    float range_mx = 0.0f;                             // range guard: largest magnitude this lane has split (track_range)
+    STAMP();
+    // Everything that is not a matrix of a block (embedding matrix and bias, the blocks' bias vectors, the anchors'
+    // biases, the final layer: 20 KB) goes to LDS with 16-byte loads, requested first so that they return first; then
+    // the rows' token tiles and the first fragments of the weight stream.  (Read straight from memory, the embedding
+    // cost every lane 64 more loads and the whole phase 9.4k cycles.)
+    static_assert(NHEAD % 4 == 0, "the staged head is copied in 16-byte pieces");
+    WeightRing<PF16> ring;
+    f32x16 xres[ROWS];
+    {
+        constexpr int PIECES = NHEAD / 4, PER = (PIECES + 256 * GROUPS - 1) / (256 * GROUPS);
+        f32x4 hv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * 256 * GROUPS;
+            hv[e] = reinterpret_cast<const f32x4 *>(P)[min(i, PIECES - 1)];
+        }
+        f32x4 t[ROWS][3];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int r = row0 + rr;
+            const bool live = r < io.R && q < n;
+            const f32x4 *tp = reinterpret_cast<const f32x4 *>(io.tile + (size_t)(live ? r : 0) * io.tile_row_stride +
+                                                             (live ? q : 0) * DGL_TILE_STRIDE);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                t[rr][i] = tp[i];
+                if (!live) t[rr][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        ring.fill(reinterpret_cast<const f32x4 *>(P + PK_STREAM16 + (size_t)w * WAVE_FRAGS * FRAG) + lane);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * 256 * GROUPS;
+            if (i < PIECES) reinterpret_cast<f32x4 *>(headv)[i] = hv[e];
+        }
+        __syncthreads();
+
+        // ---- embedding, directly in the residual layout: xres[rr][r] = X[token q][feature f(r)],
+        //      f(r) = 32w + (r&3) + 8(r>>2) + 4h;  X = b + sum_f tile[token][f] * We[c][f]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(headv + PK_EMB_W + c * EMB_IN);
+            const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float be = headv[PK_EMB_B + c];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][0][f], w0[f], acc);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][1][f], w1[f], acc);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc = fmaf(t[rr][2][f], w2[f], acc);
+                const bool live = (row0 + rr) < io.R && q < n;
+                xres[rr][r] = live ? acc + be : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
+    }
+    __syncthreads();
+    STAMP();
+
+    const int anchor0 = io.k_last, anchor1 = n - 1;    // TSP: k_last == n-1
+
+    for (int layer = 0; layer < 4; ++layer) {
+        const int PV = layer * PKV_SIZE;                 // offset of this block's bias vectors in vecs
+
+        if (layer == 1) {
+            // decoder entry: re-embed the anchor token(s) (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-446)
+            // (the stream always carries two embeddings; TSP's second equals its first and is discarded)
+            f32x16 a0[ROWS], a1[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) { a0[rr] = zero16(); a1[rr] = zero16(); }
+            gemm16_t<ROWS, ROWH, 0>(ring, XH + rd, XL + rd, a0);
+            gemm16_t<ROWS, ROWH, 16>(ring, XH + rd, XL + rd, a1);
+            __syncthreads();                           // every wave has finished reading X
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int tok = (a == 0) ? anchor0 : anchor1;
+                if (q == tok && (a == 0 || io.problem == DGL_PROBLEM_CVRP)) {
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bb = vec4(PK_ANCHOR_B - PK_VEC0 + a * D_MODEL, g);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                xres[rr][4 * g + e] = (a == 0 ? a0[rr][4 * g + e] : a1[rr][4 * g + e]) + bb[e];
+                        }
+                        store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- Q^T, K^T (transposed form) and V (normal form) for heads 2w, 2w+1 ----
+        f32x16 aq[ROWS], ak[ROWS], av[ROWS];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) { aq[rr] = zero16(); ak[rr] = zero16(); av[rr] = zero16(); }
+        {
+            f16x8 nh[ROWS], nl[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                nh[rr] = *reinterpret_cast<const f16x8 *>(XH + rr * ROWH + rd);
+                nl[rr] = *reinterpret_cast<const f16x8 *>(XL + rr * ROWH + rd);
+            }
+            Unroll<0, 8>::run([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                const f16x8 qh = as_h8(ring.template take<(6 * s) % PF16>());
+                const f16x8 ql = as_h8(ring.template take<(6 * s + 1) % PF16>());
+                const f16x8 kh = as_h8(ring.template take<(6 * s + 2) % PF16>());
+                const f16x8 kl = as_h8(ring.template take<(6 * s + 3) % PF16>());
+                const f16x8 vh = as_h8(ring.template take<(6 * s + 4) % PF16>());
+                const f16x8 vl = as_h8(ring.template take<(6 * s + 5) % PF16>());
+                f16x8 xh[ROWS], xl[ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) { xh[rr] = nh[rr]; xl[rr] = nl[rr]; }
+                if constexpr (s + 1 < 8) {
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+                        nh[rr] = *reinterpret_cast<const f16x8 *>(XH + rr * ROWH + rd + 16 * (s + 1));
+                        nl[rr] = *reinterpret_cast<const f16x8 *>(XL + rr * ROWH + rd + 16 * (s + 1));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) {
+                    aq[rr] = MFMA16(ql, xh[rr], aq[rr]);
+                    aq[rr] = MFMA16(qh, xl[rr], aq[rr]);
+                    aq[rr] = MFMA16(qh, xh[rr], aq[rr]);
+                    ak[rr] = MFMA16(kl, xh[rr], ak[rr]);
+                    ak[rr] = MFMA16(kh, xl[rr], ak[rr]);
+                    ak[rr] = MFMA16(kh, xh[rr], ak[rr]);
+                    av[rr] = MFMA16(xh[rr], vl, av[rr]);
+                    av[rr] = MFMA16(xl[rr], vh, av[rr]);
+                    av[rr] = MFMA16(xh[rr], vh, av[rr]);
+                }
+            });
+        }
+
+        STAMP();   // QKV done
+        // ---- attention, both local heads, straight from the accumulators --------------------
+        // Accumulator registers serve as split f16 operands without any lane movement: registers
+        // 8t..8t+7 of a tile whose summed index runs over its rows are one K = 16 fragment, with the
+        // same (permuted) k order in both operands.
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            f32x16 o_sel = zero16();
+            float pmx = 0.0f;                                // (attention weights lie in [0, 1]: their range is not tracked)
+            f16x8 vh[2], vl[2];                              // V[key][feature]: keys summed, two K-steps
+            split8(av[rr], 0, vh[0], vl[0], range_mx);
+            split8(av[rr], 8, vh[1], vl[1], range_mx);
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                // S^T[key j][query i] = sum_d K[j][d] Q[i][d]: the 16 d of this head are one K-step
+                f16x8 kh, kl, qh, ql;
+                split8(ak[rr], 8 * hd, kh, kl, range_mx);
+                split8(aq[rr], 8 * hd, qh, ql, range_mx);
+                f32x16 s = zero16();
+                s = MFMA16(kl, qh, s);
+                s = MFMA16(kh, ql, s);
+                s = MFMA16(kh, qh, s);
+                // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
+                // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
+                //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
+                if (n < 32) {                                    // wave-uniform: a full tile has no padded key
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int j = (m & 3) + 8 * (m >> 2) + 4 * h;
+                        s[m] = (j < n) ? s[m] : -INFINITY;
+                    }
+                }
+                float mx = s[0];
+#pragma unroll
+                for (int m = 1; m < 16; ++m) mx = fmaxf(mx, s[m]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float off = -mx * 0.36067376022224085f;
+                float sum = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    s[m] = __builtin_amdgcn_exp2f(fmaf(s[m], 0.36067376022224085f, off));
+                    sum += s[m];
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+                // O^T[d][i] = sum_j V[j][d] P[i][j]; rows d of this head are registers 8hd..8hd+7.  The weights
+                // enter unnormalised (largest = 1); the eight outputs are divided by their sum afterwards.
+                f32x16 o = zero16();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f16x8 ph, pl;
+                    split8(s, 8 * t, ph, pl, pmx);
+                    o = MFMA16(vl[t], ph, o);
+                    o = MFMA16(vh[t], pl, o);
+                    o = MFMA16(vh[t], ph, o);
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m] * inv;
+            }
+            store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr, range_mx);
+        }
+        STAMP();   // attention done
+        __syncthreads();
+        STAMP();   // barrier
+
+        // ---- multi_head_combine + residual -> o1 -------------------------------------
+        {
+            f32x16 acc[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) acc[rr] = zero16();
+            gemm16_t<ROWS, ROWH, 48>(ring, BH + rd, BL + rd, acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = vec4(PV + PKV_BC, g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (acc[rr][4 * g + e] + bb[e]);
+            }
+            // every wave passed the barrier above after its Q/K/V reads of X: X may be replaced
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
+        }
+        STAMP();   // combine done
+        __syncthreads();
+        STAMP();   // barrier
+
+        // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
+        // Software pipeline: the epilogue of chunk hc (bias, ReLU, split, LDS stores: VALU work) is
+        // interleaved with the MFMAs of the second GEMM of chunk hc-1, which do not depend on it:
+        //   G1(0) E(0) | G1(1) [E(1) || G2(0)] | G1(2) [E(2) || G2(1)] | G1(3) [E(3) || G2(2)] | G2(3)
+        // (| = workgroup barrier).  The weight stream is packed in this order.
+        {
+            f32x16 af[ROWS];
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) af[rr] = zero16();
+            auto hidden_epilogue = [&](auto hcc, f32x16 (&ah)[ROWS]) {
+                constexpr int hc = decltype(hcc)::value;
+                _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = vec4(PV + PKV_B1 + 128 * hc, g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rr = 0; rr < ROWS; ++rr) ah[rr][4 * g + e] = fmaxf(ah[rr][4 * g + e] + bb[e], 0.0f);
+                }
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr, range_mx);
+            };
+            Unroll<0, 4>::run([&](auto hcc) {
+                constexpr int hc = decltype(hcc)::value;
+                f32x16 ah[ROWS];
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
+                gemm16_t<ROWS, ROWH, (hc == 0 ? 64 : 48 + 32 * hc)>(ring, XH + rd, XL + rd, ah);
+                if constexpr (hc == 0) {
+                    hidden_epilogue(hcc, ah);
+                } else {
+                    constexpr int pc = hc - 1;                       // chunk whose second GEMM runs now
+                    _Float16 *PH = (pc & 1) ? CH : BH, *PL = (pc & 1) ? CL : BL;
+                    _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
+                    f32x4 bb[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bb[g] = vec4(PV + PKV_B1 + 128 * hc, g);
+                    // epilogue of chunk hc in 8 x ROWS x 3 pieces: K-step s handles registers 2s, 2s+1 of each
+                    // row (bias + ReLU | hi | lo and, every second step, the 8-byte stores)
+                    float v0[ROWS], v1[ROWS], t0[ROWS], t1[ROWS];
+                    unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS];
+                    auto side = [&](auto ss, auto rc, auto pp) {
+                        constexpr int st = decltype(ss)::value, rr = decltype(rc)::value, part = decltype(pp)::value;
+                        constexpr int g = st / 2, e = 2 * (st & 1);
+                        if constexpr (part == 0) {
+                            v0[rr] = fmaxf(ah[rr][2 * st] + bb[g][e], 0.0f);
+                            v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
+                        } else if constexpr (part == 1) {
+                            hq[rr] = pack_rtz(v0[rr], v1[rr]);
+                            track_range(v0[rr], v1[rr], range_mx);
+                            t0[rr] = minus_half_lo(v0[rr], hq[rr]);
+                            t1[rr] = minus_half_hi(v1[rr], hq[rr]);
+                        } else {
+                            lq[rr] = pack_rtz(t0[rr], t1[rr]);
+                            if constexpr (st & 1) {
+                                *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
+                                *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
+                            } else {
+                                hp[rr] = hq[rr];
+                                lp[rr] = lq[rr];
+                            }
+                        }
+                    };
+                    gemm16_t_with<ROWS, ROWH, 64 + 32 * hc>(ring, PH + rd, PL + rd, af, side);
+                }
+                __syncthreads();
+                if constexpr (hc == 3) gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);
+            });
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = vec4(PV + PKV_B2, g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (af[rr][4 * g + e] + bb[e]);
+            }
+            // the last barrier came after every wave's last read of X (W1 of chunk 3)
+            if (layer < 3) {
+#pragma unroll
+                for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
+            }
+        }
+        STAMP();   // FF done
+        __syncthreads();
+        STAMP();   // barrier
+    }
+    // an operand reached the binary16 range somewhere in this row's network: tell the host (it repeats the work with
+    // the binary32 kernel); every writer stores the same value
+    if (io.overflow_out != nullptr && !(range_mx < 65504.0f)) *io.overflow_out = 1;
+#ifdef PROFILE_STAMPS
+#ifdef FUSED_STAMPS
+    if (tid == 0 && io.prob_out)
+        for (int i = 0; i < 32; ++i) io.prob_out[(size_t)row0 * DGL_MAX_TOKENS + i] += i < nst ? (float)(st_[i] - st_[0]) : 0.f;
+    return;
+#else
+    if (tid == 0 && io.logits_out)
+        for (int i = 0; i < 32; ++i) io.logits_out[(size_t)row0 * DGL_MAX_TOKENS + i] = i < nst ? (float)(st_[i] - st_[0]) : 0.f;
+    return;
+#endif
+#endif
+
+    // ---- Linear_final: logit[token] = bf + sum_c X[token][c] wf[c] ---------------------
+    {
+        float wf[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = vec4(PK_FINAL_W - PK_VEC0, g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wf[4 * g + e] = v[e];
+        }
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = fmaf(xres[rr][r], wf[r], acc);
+            acc += __shfl_xor(acc, 32, 64);
+            if (h == 0) part[(w * ROWS + rr) * 32 + q] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- masked softmax, floor, greedy pick: wave w handles rows w, w+4, ... ------------
+    for (int rr = w; rr < ROWS; rr += 4) {
+        const int r = row0 + rr;
+        if (r >= io.R) continue;
+        float logit = P[PK_FINAL_B];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) logit += part[(ww * ROWS + rr) * 32 + q];
+        policy_row_output(io, r, logit);
+    }
+}
+
+
+template <int ROWS, int GROUPS>
+constexpr size_t policy16_lds_bytes() {
+    return (size_t)GROUPS * ROWS * 6 * ARR * sizeof(_Float16) + (size_t)(GROUPS * 4 * ROWS * 32 + NHEAD) * sizeof(float);
+}

@@ -42,7 +42,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define ANCHOR_FRAGS 32
 #define WAVE_FRAGS (4 * BLK_FRAGS + ANCHOR_FRAGS)   // 800
 #define PF 8                                        // f32 kernel: fragments in flight per wave
-#define PF16 16                                     // f16 kernel (every GEMM consumes a multiple of 16)
+#ifndef PF16
+#define PF16 16                                     // f16 kernel: ring depth (every GEMM starts at a multiple of 16 of the stream; blocks and the anchor section are multiples of 32 long, so 32 works too)
+#endif
 #define PK_STREAM_FRAGS (4 * WAVE_FRAGS + 32)       // + zero tail the prefetch rings may read
 #define PK_STREAM16 (PK_STREAM0 + PK_STREAM_FRAGS * FRAG)
 #define PK_TOTAL (PK_STREAM16 + PK_STREAM_FRAGS * FRAG)

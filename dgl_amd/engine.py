@@ -284,12 +284,31 @@ class TspEngine:
         check(self.lib.dgl_tsp_tour_length(ctypes.byref(st), ptr(self.length), stream_ptr()), "dgl_tsp_tour_length")
         return self.length
 
+    def fused_decode_available(self) -> bool:
+        """dgl_tsp_greedy_decode takes rows of at most 32 tokens under the split-f16 arithmetic whose step arrays fit
+        two rows to a workgroup's LDS.  Opt-in (DGL_FUSED_DECODE=1): measured 2-4 % SLOWER than two launches per
+        decision at 512 rows x 1000 nodes - inside one long-running kernel the workgroups drift apart, the weight
+        stream loses the lock-step sharing of the per-XCD L2 and every matrix phase takes ~35 % more cycles, which
+        outweighs the two kernel boundaries saved per decision."""
+        if os.environ.get("DGL_FUSED_DECODE", "0") != "1":
+            return False
+        per_row = 4 * (self.N + (self.knn + 1) * TILE_STRIDE + 128 + 2 * 192 + 8 + 2 * self.N)
+        return self.out_w == MAX_TOKENS and self.arithmetic == _lib.ARITH_SPLIT_F16 and 2 * per_row <= 150 * 1024
+
     @on_own_device
     @range_guarded
     def greedy_rollout(self, policy: PackedPolicy, start: torch.Tensor) -> torch.Tensor:
-        """Whole greedy decode (beam 1): N-1 policy decisions, everything stays on the device."""
+        """Whole greedy decode (beam 1): N-1 policy decisions, everything stays on the device.  One launch for the
+        whole loop (dgl_tsp_greedy_decode) where that kernel applies, otherwise two launches per decision."""
         self.reset()
         self.step(start)
+        if self.t < self.N and self.fused_decode_available():
+            io = self.policy_io(want_logits=False, want_prob=False)
+            check(self.lib.dgl_tsp_greedy_decode(ctypes.byref(self.state["struct"]), ptr(policy.packed), ctypes.byref(io),
+                                                 self.t, self.N, self.knn, stream_ptr()), "dgl_tsp_greedy_decode")
+            self.t = self.N
+            self.tile_t = -1
+            return self.tour_length()
         while self.t < self.N:
             self.forward(policy, want_logits=False, want_prob=False)
             self.step(self.selected)

@@ -260,6 +260,20 @@ DGL_API int dgl_policy_forward(const float *packed_weights, const dgl_policy_io_
 DGL_API int dgl_policy_scatter_probs(const dgl_policy_io_t *io, const float *prob, float *dense_out,
                              int32_t A, dgl_stream_t stream);
 
+/* ---------------------------------------------------------------- fused greedy decode
+ * The decode loop of TSPTester.beamsearch_tour_nodes_shortest for beam 1 (TSP/TSPTester.py:163-180: model(...),
+ * arg-max, env.step(...), repeated) in one launch: for t = t_done .. t_end-1 the policy decision on the neighbourhood
+ * the previous step built (as dgl_policy_forward, DGL_ARITH_SPLIT_F16, greedy pick to io->selected_out) and then
+ * dgl_tsp_step(st, io->selected_out, t + 1, knn, io->idx_last, io->tile).  Bit-identical to that sequence of calls.
+ *  st  : state after t_done >= 1 steps; io->idx_last (row stride knn) and io->tile (row stride (knn+1)*DGL_TILE_STRIDE)
+ *        hold the neighbourhood of that state (dgl_tsp_step / dgl_tsp_knn wrote them) and are overwritten;
+ *  io  : problem TSP, R, N as in st; n / k_last are set per step by the kernel; logits_out / prob_out are ignored;
+ *        overflow_out as for dgl_policy_forward.  knn + 1 <= DGL_MAX_TOKENS.
+ * Returns DGL_ERR_UNSUPPORTED when two rows' step arrays do not fit a workgroup's LDS (N above about 4000): use the
+ * step-by-step calls then. */
+DGL_API int dgl_tsp_greedy_decode(const dgl_tsp_state_t *st, const float *packed_weights, const dgl_policy_io_t *io,
+                                  int32_t t_done, int32_t t_end, int32_t knn, dgl_stream_t stream);
+
 /* ------------------------------------------------------- general forward / training step
  * The same network for ANY number of tokens per row (2 <= n <= 256; e.g. knn = depot_knn = 100,
  * CVRP/train.py:130-131), evaluated as a sequence of plain f32 matrix kernels over the flattened

@@ -143,3 +143,24 @@ def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     assert frac >= min_identical
     assert rel < 1e-4
     np.testing.assert_allclose(length[same], case["length"][same], rtol=2e-6)
+
+
+def test_fused_greedy_decode_is_bit_identical(device, monkeypatch):
+    """dgl_tsp_greedy_decode (the whole decode loop in one launch) against two launches per decision: the same device
+    code runs in both, so tours and lengths must be equal bit for bit; odd row count, neighbourhoods that shrink at
+    the end of the tour."""
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from dgl_amd._lib import PROBLEM_TSP
+    case, weights = load_golden("tsp_n100_b64_nn")
+    xy = torch.from_numpy(case["xy"][:33]).to(device)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    start = torch.from_numpy(case["start"]).to(device=device, dtype=torch.int32).repeat(33)
+    eng = TspEngine(xy, 1, 30)
+    monkeypatch.setenv("DGL_FUSED_DECODE", "0")
+    ref_len = eng.greedy_rollout(pol, start).clone()
+    ref_tour = eng.state["tour"].clone()
+    monkeypatch.setenv("DGL_FUSED_DECODE", "1")
+    assert eng.fused_decode_available()
+    got_len = eng.greedy_rollout(pol, start).clone()
+    assert torch.equal(eng.state["tour"], ref_tour) and torch.equal(got_len, ref_len)
+    assert np.array_equal(ref_tour.cpu().numpy(), case["tour"][:33])
