@@ -122,6 +122,8 @@ def load() -> ctypes.CDLL:
                        "(there is no fallback path)")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("DGL_AMD_ALLOW_MISSING") == "1" and not hasattr(lib, name):
+            continue                     # (A/B tools only: an older build of the library lacks the newest entry points)
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -162,10 +162,16 @@ __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Flo
     __builtin_amdgcn_sched_barrier(0);
 }
 
-#ifdef PROFILE_STAMPS
+// PROFILE_STAMPS=1: one stamp per phase of every block; =2: fine stamps inside block 2 only (FF per chunk)
+#if defined(PROFILE_STAMPS) && PROFILE_STAMPS == 2
+#define STAMP() do { } while (0)
+#define STAMP2() do { if (tid == 0 && layer == 2 && nst < 32) st_[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(PROFILE_STAMPS)
 #define STAMP() do { if (tid == 0 && nst < 32) st_[nst++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP2() do { } while (0)
 #else
 #define STAMP() do { } while (0)
+#define STAMP2() do { } while (0)
 #endif
 
 // The network for the rows of one workgroup: rows (wg * GROUPS + grp) * ROWS ...  `lds`: the workgroup's dynamic LDS
@@ -267,6 +273,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
 
     for (int layer = 0; layer < 4; ++layer) {
         const int PV = layer * PKV_SIZE;                 // offset of this block's bias vectors in vecs
+        STAMP2();  // block start
 
         if (layer == 1) {
             // decoder entry: re-embed the anchor token(s) (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-446)
@@ -343,6 +350,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         }
 
         STAMP();   // QKV done
+        STAMP2();
         // ---- attention, both local heads, straight from the accumulators --------------------
         // Accumulator registers serve as split f16 operands without any lane movement: registers
         // 8t..8t+7 of a tile whose summed index runs over its rows are one K = 16 fragment, with the
@@ -404,8 +412,10 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             store_split(o_sel, BH + rr * ROWH + wr, BL + rr * ROWH + wr, range_mx);
         }
         STAMP();   // attention done
+        STAMP2();
         __syncthreads();
         STAMP();   // barrier
+        STAMP2();
 
         // ---- multi_head_combine + residual -> o1 -------------------------------------
         {
@@ -426,8 +436,10 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
         }
         STAMP();   // combine done
+        STAMP2();
         __syncthreads();
         STAMP();   // barrier
+        STAMP2();
 
         // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
         // Software pipeline: the epilogue of chunk hc (bias, ReLU, split, LDS stores: VALU work) is
@@ -458,6 +470,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
                 gemm16_t<ROWS, ROWH, (hc == 0 ? 64 : 48 + 32 * hc)>(ring, XH + rd, XL + rd, ah);
+                STAMP2();  // G1(hc) done
                 if constexpr (hc == 0) {
                     hidden_epilogue(hcc, ah);
                 } else {
@@ -495,8 +508,11 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
                     };
                     gemm16_t_with<ROWS, ROWH, 64 + 32 * hc>(ring, PH + rd, PL + rd, af, side);
                 }
+                STAMP2();  // epilogue / G2(hc-1) done
                 __syncthreads();
+                STAMP2();  // barrier
                 if constexpr (hc == 3) gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);
+                if constexpr (hc == 3) STAMP2();  // G2(3) done
             });
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -513,8 +529,10 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             }
         }
         STAMP();   // FF done
+        STAMP2();
         __syncthreads();
         STAMP();   // barrier
+        STAMP2();
     }
     // an operand reached the binary16 range somewhere in this row's network: tell the host (it repeats the work with
     // the binary32 kernel); every writer stores the same value
