@@ -100,6 +100,7 @@ def measured_peaks(dev):
     lib.dglb_copy.argtypes = [vp, vp, i64, i32, i32, vp]
     lib.dglb_mfma_f16.argtypes = [i32, i32, vp, vp]
     lib.dglb_mfma_f32.argtypes = [i32, i32, vp, vp]
+    lib.dglb_mfma_f16_16.argtypes = [i32, i32, vp, vp]
     st = torch.cuda.current_stream().cuda_stream
     n = 1 << 28                                               # 1 GiB per array: far beyond the 256 MiB Infinity Cache
     a, b, c = (torch.rand(n, device=dev) for _ in range(3))
@@ -122,11 +123,13 @@ def measured_peaks(dev):
     blocks, it16, it32 = 2048, 4000, 1000
     # ~0.5 s of back-to-back launches on random operands first: the clock the chip settles on under this load
     t16 = timed(lambda: lib.dglb_mfma_f16(blocks, it16, sink.data_ptr(), st), 60)
+    t16b = timed(lambda: lib.dglb_mfma_f16_16(blocks, it16, sink.data_ptr(), st), 60)
     t32 = timed(lambda: lib.dglb_mfma_f32(blocks, it32, sink.data_ptr(), st), 20)
     fl16 = blocks * 4 * it16 * 4 * 2.0 * 32 * 32 * 16
     fl32 = blocks * 4 * it32 * 4 * 2.0 * 32 * 32 * 2
     return {"hbm_triad_GBs": 3 * 4 * n / t_triad / 1e9, "hbm_copy_GBs": 2 * 4 * n / t_copy / 1e9,
-            "mfma_f16_32x32x16_TFLOPs": fl16 / t16 / 1e12, "mfma_f32_32x32x2_TFLOPs": fl32 / t32 / 1e12,
+            "mfma_f16_32x32x16_TFLOPs": fl16 / t16 / 1e12, "mfma_f16_16x16x32_TFLOPs": blocks * 4 * it16 * 8 * 2.0 * 16 * 16 * 32 / t16b / 1e12,
+            "mfma_f32_32x32x2_TFLOPs": fl32 / t32 / 1e12,
             "nominal": {"hbm_GBs": PEAK_HBM_GBS, "mfma_f16_TFLOPs": PEAK_F16_MATRIX_TFLOPS,
                         "mfma_f32_TFLOPs": PEAK_FP32_MATRIX_TFLOPS},
             "note": "float4 triad / copy over 1 GiB arrays; register-resident matrix instructions on random operands, "

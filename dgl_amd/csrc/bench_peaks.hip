@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void mfma_f16_kernel(int iters, float *__restr
         for (int e = 0; e < 16; ++e) s += acc[k][e];
     if (s == 123.456f) sink[0] = s;                       // keeps the loop alive
 }
+// the same flops per wave with the 16x16x32 shape: eight independent 16x16 accumulators
+__global__ __launch_bounds__(256) void mfma_f16_16_kernel(int iters, float *__restrict__ sink) {
+    f16x8 a[4], b[4];
+    f32x4 acc[8];
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;
+    for (int k = 0; k < 4; ++k) {
+        for (int e = 0; e < 8; ++e) {
+            a[k][e] = (_Float16)(((int)(hash32(t * 64 + k * 16 + e) & 0xFFFF) - 32768) * (1.0f / 16384.0f));
+            b[k][e] = (_Float16)(((int)(hash32(t * 64 + k * 16 + e + 8) & 0xFFFF) - 32768) * (1.0f / 16384.0f));
+        }
+    }
+    for (int k = 0; k < 8; ++k)
+        for (int e = 0; e < 4; ++e) acc[k][e] = 0.0f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[k & 3], b[k >> 1], acc[k], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int k = 0; k < 8; ++k)
+        for (int e = 0; e < 4; ++e) s += acc[k][e];
+    if (s == 123.456f) sink[0] = s;
+}
 __global__ __launch_bounds__(256) void mfma_f32_kernel(int iters, float *__restrict__ sink) {
     float a[4], b[4];
     f32x16 acc[4];
@@ -98,6 +120,11 @@ PEAKS_API int dglb_copy(float *a, const float *b, int64_t n, int unroll, int nt,
 // blocks of 4 waves; flops = blocks * 4 waves * iters * 4 * (2 * 32 * 32 * K)
 PEAKS_API int dglb_mfma_f16(int blocks, int iters, float *sink, void *stream) {
     hipLaunchKernelGGL(mfma_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// iters x 8 MFMAs of 2 * 16 * 16 * 32 flops per wave
+PEAKS_API int dglb_mfma_f16_16(int blocks, int iters, float *sink, void *stream) {
+    hipLaunchKernelGGL(mfma_f16_16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sink);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 PEAKS_API int dglb_mfma_f32(int blocks, int iters, float *sink, void *stream) {
