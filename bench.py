@@ -266,7 +266,8 @@ def run_problem(problem, args, world, rank, dev, dist):
         out["roofline_knn"]["bytes_note"] = ("per-row figure 28 m + m/4 + 8 (k + kd) with a demand read per node; the "
                                              "kernel reads the candidates' demand only, about 24 m bytes move")
     if not args.no_aux and world == 1:
-        out["roofline_knn"]["saturating_batch"] = knn_saturating(dev, problem, N, knn)
+        out["roofline_knn"]["saturating_batch"] = sat = knn_saturating(dev, problem, N, knn)
+        sat["traffic"] = pmc_traffic(problem, N, sat["rows"], knn, "step_kernel")
         if split and not cvrp:                   # the f32-input kernel on tiles of the same shape, outside the timed region
             eng.reset(); eng.step(start)
             eng.arithmetic = ARITH_F32
