@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libdgl_amd.so")
 SOURCES = ["api.cpp", "tsp_state.hip", "cvrp_state.hip", "policy.hip", "policy16.hip", "train.hip", "augment.hip", "selfimprove.hip", "beam.hip", "rollout.hip"]
-HEADERS = ["common.h", "select.h", "state_common.h", "policy_layout.h", "policy16_body.h", "tsp_step_body.h", os.path.join("..", "..", "include", "dgl_amd.h")]
+HEADERS = ["common.h", "select.h", "state_common.h", "policy_layout.h", "policy16_body.h", "tsp_step_body.h", "split_f16.h", os.path.join("..", "..", "include", "dgl_amd.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",            # every FMA is explicit: results must not depend on contraction

@@ -2,6 +2,7 @@
 // code runs as a kernel of its own (policy16.hip) and inside the fused decode kernel (rollout.hip).
 #pragma once
 #include "policy_layout.h"
+#include "split_f16.h"
 
 #define LDH 136                               // LDS row stride in halfs
 #define ARR (32 * LDH)                        // halfs per [32 tokens][128 features] image
@@ -12,28 +13,6 @@ __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x
 
 #define NHEAD PK_STREAM0                         // embedding + bias vectors + final weights: staged in LDS (multiple of 4)
 
-// Split of activations: hi = binary16(v) rounded towards zero (one packed conversion for two values),
-// lo = binary16(v - hi), the difference formed exactly by one mixed-precision FMA that reads hi
-// straight from the packed register: four VALU operations per pair, 22 significant bits kept.
-// Magnitudes above 65504 saturate in hi and continue in lo; below 2^-14 the absolute accuracy is 2^-24.
-__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-// a - (low / high half of hh, read as binary16), exact in binary32
-__device__ __forceinline__ float minus_half_lo(float a, unsigned hh) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
-    return r;
-}
-__device__ __forceinline__ float minus_half_hi(float a, unsigned hh) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(a));
-    return r;
-}
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
-    hi = pack_rtz(a, b);
-    lo = pack_rtz(minus_half_lo(a, hi), minus_half_hi(b, hi));
-}
 // Range guard: the largest operand magnitude this lane has split, as binary32 bits of a non-negative float (one
 // v_max3_f32 with |.| source modifiers per pair of values).  65504 is where the round-towards-zero conversion to
 // binary16 saturates.
@@ -45,8 +24,6 @@ __device__ __forceinline__ void track_range(float a, float b, float &mx) {
     mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), __builtin_fabsf(b));
 #endif
 }
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // registers r0..r0+7 of an accumulator tile as one MFMA operand fragment (hi and lo)
 __device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8 &lo, float &mx) {
     u32x4 h, l;

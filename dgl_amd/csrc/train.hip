@@ -4,35 +4,87 @@
 // inference when a row has more than one 32-token tile (knn + depot_knn + 2 > 32).
 //
 // Unlike the fused decode kernels this path is a sequence of plain kernels over the flattened
-// token axis (M = R*n tokens): one strided f32-MFMA GEMM kernel serves the three products of a
-// linear layer (Y = X W^T, dX = dY W, dW += dY^T X), attention runs per (row, head) with the
-// probabilities kept for the backward pass, the output stage computes the teacher's probability
-// and the gradient of  -mean(log p_teacher)  with respect to the logits.  Everything is binary32
-// (v_mfma_f32_32x32x2_f32 = FMA chains); weight gradients are accumulated with float atomics.
+// token axis (M = R*n tokens): one strided GEMM kernel (split-binary16 MFMA, binary32 accumulation)
+// serves the three products of a linear layer (Y = X W^T, dX = dY W, dW += dY^T X), attention runs
+// per (row, head) and recomputes its probabilities in the backward pass, the output stage computes
+// the teacher's probability and the gradient of  -mean(log p_teacher)  with respect to the logits.
+// Sums over tokens (weight and bias gradients) are formed as partial sums per chunk of tokens and
+// added in a fixed order: no float atomics, so gradients are bit-reproducible from run to run.
 #include "policy_layout.h"
+#include "split_f16.h"
 
 #include <mutex>
 
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define HEADS 8
 #define HDIM 16
 
 // ------------------------------------------------------------------------------- GEMM
-// C[i][j] (op)= sum_kk A(i,kk) B(kk,j),  A(i,kk) = A[i*sai + kk*sak],  B(kk,j) = B[kk*sbk + j*sbn],
-// i < I, j < J, kk in the z-th chunk of [0, KK).  64x64 output tile per workgroup (4 waves, each a
-// 32x32 MFMA tile), K staged through LDS 32 at a time.
-//   mode 0: C = acc (+ bias[j]) (ReLU) (+ add[i][j]);  mode 1: C += acc;  mode 2: atomicAdd(C, acc)
+// C[i][j] (op)= sum over segments s, kk of A_s(i,kk) B_s(kk,j),  A(i,kk) = A[i*sai + kk*sak],  B(kk,j) = B[kk*sbk + j*sbn],
+// i < I, j < J, kk in the z-th chunk of [0, KK).  64x64 output tile per workgroup (4 waves, each a 32x32 MFMA tile),
+// K staged 32 at a time through LDS.
+//
+// Arithmetic: binary32 operands are scaled by a power of two, split into binary16 halves (hi + lo, 22 significant
+// bits) when they are staged, and multiplied as lo*hi + hi*lo + hi*hi on the f16 matrix cores with binary32
+// accumulation - the fused decode kernel's arithmetic, at 16/3 of the f32-input matrix rate.  binary16 has a narrow
+// exponent range (gradients of 1e-6 would lose their low half, activations beyond 65504 saturate), so every operand
+// that is an activation or a gradient comes with a device scalar holding an upper bound of its magnitude (written by
+// the kernel that produced it, atomic max: order-independent) and is scaled so that this bound lands at 2^10; the
+// accumulator is scaled back exactly.  Weights go in unscaled.
+//   mode 0: C = acc (+ bias[j]) (ReLU) (+ add[i][j]);  mode 1: C += acc;
+//   mode 3: C + z * part_stride = acc of K-chunk z (partial products, summed in fixed order by reduce_partials_kernel:
+//           no float atomics anywhere, results are bit-reproducible)
+#define GEMM_SEGS 3
 struct GemmArgs {
-    const float *A, *B;
+    const float *A[GEMM_SEGS], *B[GEMM_SEGS];
+    const float *amax_a[GEMM_SEGS];   // per segment: bound of |A_s| (device scalar) or NULL = unscaled
+    const float *amax_b;              // bound of |B| or NULL
+    int nseg;
     float *C;
     const float *bias, *add;
+    const float *gate;                // mode 0: C = 0 where gate[i][j] <= 0 (same layout as C), the ReLU's backward; or NULL
+    float *colsum_part;               // A with contiguous rows only: colsum_part[z][i] = sum over chunk z of A(i, kk), or NULL
+    float *amax_c;                    // raised to max |C written| (mode 0 / 1) or NULL
     int I, J, KK;
     long sai, sak, sbk, sbn;
     int ldc, ldadd;
     int mode, relu, kchunk;
+    long part_stride;
+    int launch_seq;                   // debug builds: number of the launch
 };
 
-#define GBK 32      // K-extent of one LDS stage
+#ifndef GBK
+#define GBK 64      // K-extent of one LDS stage
+#endif
+#define LDK (GBK + 8)   // halfs per LDS row: 8 of padding (conflict-free 16-byte operand reads)
+#define NG (GBK / 16)   // groups of four elements per thread, operand and stage
+#define GEMM_LDS_BYTES (4 * 64 * LDK * 2)
+
+// power of two that brings a magnitude bound to [2^10, 2^11): exact scaling, 6 binades of headroom below the
+// binary16 maximum, 24 binades of full 22-bit precision below the bound
+__device__ __forceinline__ float pow2_scale_for(float amax) {
+    if (!(amax > 0.0f) || !(amax < INFINITY)) return 1.0f;
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;
+    e = max(min(10 - e, 60), -60);
+    return __uint_as_float((unsigned)(e + 127) << 23);
+}
+// A magnitude bound is kept as AMAX_SUB partial maxima, 128 bytes apart: thousands of waves raise one bound, and on a
+// single address their atomics (and the reads queued behind them) serialise in one L2 channel.  A workgroup raises
+// the part chosen by its index; the plain read first keeps all but the few that really raise it away from the atomic
+// unit (a stale read only costs an atomic).  v >= 0: unsigned order = numeric order.
+#define AMAX_SUB 16
+#define AMAX_SUB_STRIDE 32                          // floats between parts
+#define AMAX_STRIDE (AMAX_SUB * AMAX_SUB_STRIDE)    // floats per bound
+__device__ __forceinline__ void atomic_max_abs(float *bound, float v) {
+    float *slot = bound + (blockIdx.x & (AMAX_SUB - 1)) * AMAX_SUB_STRIDE;
+    if (v > *reinterpret_cast<volatile float *>(slot)) atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(v));
+}
+__device__ __forceinline__ float amax_read(const float *bound) {
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < AMAX_SUB; ++i) m = fmaxf(m, bound[i * AMAX_SUB_STRIDE]);
+    return m;
+}
 
 // four consecutive elements of a strided operand tile, along k (k_fast) or along the tile's row index m:
 // one 16-byte load where the four exist and are aligned, guarded scalars otherwise
@@ -51,138 +103,366 @@ __device__ __forceinline__ float4 gemm_load4(const float *__restrict__ P, long s
     return v;
 }
 
+// Debug build (-DGEMM_STAMPS): wave 0 of every workgroup records the shader clock at the phase boundaries of its
+// tile; dgl_debug_gemm_stamps copies the records of the last 64 launches out.
+#ifdef GEMM_STAMPS
+#define GEMM_STAMP_WGS 4096
+static __device__ unsigned long long gemm_stamp_buf[64 * GEMM_STAMP_WGS * 8];
+#define GSTAMP(i)                                                                                                           \
+    do {                                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < GEMM_STAMP_WGS)                                                                \
+            gemm_stamp_buf[((size_t)(g.launch_seq & 63) * GEMM_STAMP_WGS + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GSTAMP(i)
+#endif
+
+// One 64x64 tile of one product.  AK / BK: the operand's k index is the contiguous one in memory (else its row index
+// is).  FULL: the tile lies inside both operands, every stage is a whole one and every group of four is a 16-byte
+// load - the sixteen loads of a stage are then issued back to back with nothing between them (a guard around each
+// load would serialise them on the memory latency); the other tiles take guarded loads.
+template <bool AK, bool BK, bool FULL>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const int j0, const int z, _Float16 *lds) {
+    _Float16 *AH = lds, *AL = AH + 64 * LDK, *BH = AL + 64 * LDK, *BL = BH + 64 * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int k_lo = z * g.kchunk, k_hi = min(g.KK, k_lo + g.kchunk);
+    const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
+    float sa = 1.0f, sb = 1.0f;
+    f32x16 acc = zero16();
+    // staging map: each thread moves eight groups of four elements per operand and stage.  An operand whose k index
+    // is contiguous in memory: four consecutive k of one row per group (32 groups per row, rows tid/32 + 8 e).  An
+    // operand whose row index is contiguous: four consecutive rows at k = 32 (e/2) + 2 (tid/16) and at k + 1, so that
+    // a (k, k+1) pair of every row splits into one packed word.  The next stage is fetched into registers while the
+    // MFMAs of the current one run.
+    auto map_m = [&](bool k_fast, int e) { return k_fast ? tid / (GBK / 4) + (1024 / GBK) * e : (tid & 15) * 4; };
+    auto map_k = [&](bool k_fast, int e) { return k_fast ? (tid % (GBK / 4)) * 4 : 32 * (e >> 1) + 2 * (tid >> 4) + (e & 1); };
+    // splits and stores one group (k-contiguous operand: v0) or one pair of groups (row-contiguous operand: v0 at k, v1 at k + 1)
+    auto stage_group = [&](_Float16 *H, _Float16 *L, bool k_fast, int e, const float4 &v0, const float4 &v1, float s) {
+        if (k_fast) {
+            unsigned h0, l0, h1, l1;
+            split2(v0.x * s, v0.y * s, h0, l0);
+            split2(v0.z * s, v0.w * s, h1, l1);
+            const int o = map_m(true, e) * LDK + map_k(true, e);
+            *reinterpret_cast<u32x2 *>(H + o) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(L + o) = u32x2{l0, l1};
+        } else {
+            const float k0v[4] = {v0.x, v0.y, v0.z, v0.w}, k1v[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hi, lo;
+                split2(k0v[c] * s, k1v[c] * s, hi, lo);
+                const int o = (map_m(false, e) + c) * LDK + map_k(false, e);
+                *reinterpret_cast<unsigned *>(H + o) = hi;
+                *reinterpret_cast<unsigned *>(L + o) = lo;
+            }
+        }
+    };
+    float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                // running sums over k of the A rows this thread stages
+    auto add_csum = [&](const float4 &v) { csum[0] += v.x; csum[1] += v.y; csum[2] += v.z; csum[3] += v.w; };
+    const bool want_csum = !AK && g.colsum_part != nullptr;
+    for (int seg = 0; seg < g.nseg; ++seg) {
+        const float *A = g.A[seg], *B = g.B[seg];
+        float4 ra[NG], rb[NG];                                 // FULL only: the next stage, in flight during the MFMAs
+        auto fetch = [&](int k0) {
+            const float *pa = A + (long)(i0 + map_m(AK, 0)) * g.sai + (long)(k0 + map_k(AK, 0)) * g.sak;
+            const float *pb = B + (long)(j0 + map_m(BK, 0)) * g.sbn + (long)(k0 + map_k(BK, 0)) * g.sbk;
+#pragma unroll
+            for (int e = 0; e < NG; ++e)
+                ra[e] = *reinterpret_cast<const float4 *>(pa + (long)(map_m(AK, e) - map_m(AK, 0)) * g.sai +
+                                                          (long)(map_k(AK, e) - map_k(AK, 0)) * g.sak);
+#pragma unroll
+            for (int e = 0; e < NG; ++e)
+                rb[e] = *reinterpret_cast<const float4 *>(pb + (long)(map_m(BK, e) - map_m(BK, 0)) * g.sbn +
+                                                          (long)(map_k(BK, e) - map_k(BK, 0)) * g.sbk);
+        };
+        if (FULL) fetch(k_lo);
+        if (seg == 0) {
+            // operand scales (one per product: the segments share the larger bound), read while the first stage's
+            // loads are in flight, and the values the epilogue combines with the product
+            float bound_a = 0.0f;
+            bool scaled_a = false;
+            for (int s = 0; s < g.nseg; ++s)
+                if (g.amax_a[s]) { bound_a = fmaxf(bound_a, amax_read(g.amax_a[s])); scaled_a = true; }
+            if (scaled_a) sa = pow2_scale_for(bound_a);
+            if (g.amax_b) sb = pow2_scale_for(amax_read(g.amax_b));
+            GSTAMP(1);
+        }
+        for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
+            if (FULL) {
+                if (want_csum) {
+#pragma unroll
+                    for (int e = 0; e < NG; ++e) add_csum(ra[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < NG; e += AK ? 1 : 2) stage_group(AH, AL, AK, e, ra[e], ra[AK ? e : e + 1], sa);
+#pragma unroll
+                for (int e = 0; e < NG; e += BK ? 1 : 2) stage_group(BH, BL, BK, e, rb[e], rb[BK ? e : e + 1], sb);
+            } else {
+                // edge tile: group by group, guarded, nothing kept in flight
+                const bool a_vec = ((reinterpret_cast<size_t>(A) & 15) == 0) && (((AK ? g.sai : g.sak) & 3) == 0);
+                const bool b_vec = ((reinterpret_cast<size_t>(B) & 15) == 0) && (((BK ? g.sbn : g.sbk) & 3) == 0);
+#pragma unroll 1
+                for (int e = 0; e < NG; e += AK ? 1 : 2) {
+                    const float4 v0 = gemm_load4(A, g.sai, g.sak, AK, a_vec, i0 + map_m(AK, e), k0 + map_k(AK, e), g.I, k_hi);
+                    const float4 v1 = AK ? v0 : gemm_load4(A, g.sai, g.sak, AK, a_vec, i0 + map_m(AK, e + 1), k0 + map_k(AK, e + 1), g.I, k_hi);
+                    if (want_csum) { add_csum(v0); add_csum(v1); }
+                    stage_group(AH, AL, AK, e, v0, v1, sa);
+                }
+#pragma unroll 1
+                for (int e = 0; e < NG; e += BK ? 1 : 2) {
+                    const float4 v0 = gemm_load4(B, g.sbn, g.sbk, BK, b_vec, j0 + map_m(BK, e), k0 + map_k(BK, e), g.J, k_hi);
+                    const float4 v1 = BK ? v0 : gemm_load4(B, g.sbn, g.sbk, BK, b_vec, j0 + map_m(BK, e + 1), k0 + map_k(BK, e + 1), g.J, k_hi);
+                    stage_group(BH, BL, BK, e, v0, v1, sb);
+                }
+            }
+            if (k0 == k_lo && seg == 0) GSTAMP(2);
+            __syncthreads();
+            if (k0 == k_lo && seg == 0) GSTAMP(3);
+            if (FULL && k0 + GBK < k_hi) fetch(k0 + GBK);
+            const int ksteps = FULL ? GBK / 16 : (min(GBK, k_hi - k0) + 15) / 16;
+#pragma unroll 2
+            for (int t = 0; t < ksteps; ++t) {
+                const int oa = (wi + q) * LDK + 16 * t + 8 * h, ob = (wj + q) * LDK + 16 * t + 8 * h;
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(AH + oa), al = *reinterpret_cast<const f16x8 *>(AL + oa);
+                const f16x8 bh = *reinterpret_cast<const f16x8 *>(BH + ob), bl = *reinterpret_cast<const f16x8 *>(BL + ob);
+                acc = MFMA16(al, bh, acc);
+                acc = MFMA16(ah, bl, acc);
+                acc = MFMA16(ah, bh, acc);
+            }
+            __syncthreads();
+        }
+    }
+    GSTAMP(4);
+    const float unscale = 1.0f / (sa * sb);                   // exact: powers of two within 2^+-120
+    const int j = j0 + wj + q;
+    float cmax = 0.0f;
+    if (j < g.J) {
+        float *Cz = g.C + (g.mode == 3 ? (long)z * g.part_stride : 0);
+        // everything the epilogue reads is loaded before its first store: C, add and gate may alias as far as the
+        // compiler can tell, and a load placed after a store would wait for its own round trip sixteen times over
+        float other[16], gate[16];
+        const float bias_j = (g.mode == 0 && g.bias) ? g.bias[j] : 0.0f;
+        const float *src = g.mode == 1 ? g.C : g.add;
+        const int lds_ = g.mode == 1 ? g.ldc : g.ldadd;
+        const bool has_other = g.mode == 1 || (g.mode == 0 && g.add != nullptr), has_gate = g.mode == 0 && g.gate != nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool in = FULL || i < g.I;
+            other[r] = (has_other && in) ? src[(long)i * lds_ + j] : 0.0f;
+            gate[r] = (has_gate && in) ? g.gate[(long)i * g.ldc + j] : 1.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (!FULL && i >= g.I) continue;
+            float v = acc[r] * unscale;
+            if (g.mode == 0) {
+                v += bias_j;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (!(gate[r] > 0.0f)) v = 0.0f;
+            }
+            v = other[r] + v;
+            Cz[(long)i * g.ldc + j] = v;
+            cmax = fmaxf(cmax, fabsf(v));
+        }
+    }
+    GSTAMP(5);
+    if (g.amax_c) {
+        cmax = wave_max_f32(cmax);
+        if (lane == 0) atomic_max_abs(g.amax_c, cmax);
+    }
+    GSTAMP(6);
+    if (!AK && g.colsum_part && j0 == 0) {
+        // sum over this chunk's k of every A row: the 16 threads that staged a row add up in a fixed order
+        float *red = reinterpret_cast<float *>(lds);             // [16][64]; the last stage's reads ended at the barrier
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[(tid >> 4) * 64 + (tid & 15) * 4 + c] = csum[c];
+        __syncthreads();
+        if (tid < 64 && i0 + tid < g.I) {
+            float s = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) s += red[o * 64 + tid];
+            g.colsum_part[(long)z * g.I + i0 + tid] = s;
+        }
+    }
+}
+
 // Several independent products share one launch: workgroup `blockIdx.x` belongs to the product whose block
-// range [first[b], first[b+1]) contains it.
+// range [first[b], first[b+1]) contains it.  Consecutive workgroups go to the chip's eight dies in turn, each with
+// its own L2, so the tiles that read the same operand data are numbered eight apart: the 64-column tiles of one
+// row tile (they share the A tile) when the reduction is short, all tiles of one K-chunk when it is split.
 #define GEMM_BATCH_MAX 6
 struct GemmBatch {
     GemmArgs g[GEMM_BATCH_MAX];
     int first[GEMM_BATCH_MAX + 1];
     int count;
 };
+static inline __host__ __device__ int gemm_round8(int v) { return (v + 7) & ~7; }
+static inline __host__ __device__ int gemm_blocks(const GemmArgs &g) {
+    const int gx = (g.I + 63) / 64, gy = (g.J + 63) / 64, zs = (g.KK + g.kchunk - 1) / g.kchunk;
+    return zs > 1 ? gx * gy * gemm_round8(zs) : gemm_round8(gx) * gy;
+}
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
-    __shared__ float As[64][GBK + 1], Bs[64][GBK + 1];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    extern __shared__ __align__(16) _Float16 gemm_lds[];
     int b = 0;
     while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
-    const GemmArgs g = batch.g[b];
+    const GemmArgs &g = batch.g[b];
+    GSTAMP(0);
     const int local = blockIdx.x - batch.first[b];
-    const int gx = (g.I + 63) / 64, gy = (g.J + 63) / 64;
-    const int i0 = (local % gx) * 64, j0 = ((local / gx) % gy) * 64;
-    const int k_lo = (local / (gx * gy)) * g.kchunk, k_hi = min(g.KK, k_lo + g.kchunk);
-    const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
-    f32x16 acc = zero16();
-    // staging map: each thread moves two groups of four elements per operand and stage; the four run along
-    // whichever index is contiguous in memory.  The next stage is fetched into registers while the MFMAs of the
-    // current one run.
-    const bool a_k_fast = g.sak == 1, b_k_fast = g.sbk == 1;
-    const bool a_vec = ((reinterpret_cast<size_t>(g.A) & 15) == 0) && (((a_k_fast ? g.sai : g.sak) & 3) == 0);
-    const bool b_vec = ((reinterpret_cast<size_t>(g.B) & 15) == 0) && (((b_k_fast ? g.sbn : g.sbk) & 3) == 0);
-    int am[2], ak[2], bm[2], bk[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int o = tid + 256 * e;
-        if (a_k_fast) { am[e] = o >> 3; ak[e] = (o & 7) * 4; } else { ak[e] = o >> 4; am[e] = (o & 15) * 4; }
-        if (b_k_fast) { bm[e] = o >> 3; bk[e] = (o & 7) * 4; } else { bk[e] = o >> 4; bm[e] = (o & 15) * 4; }
+    const int gx = (g.I + 63) / 64, gy = (g.J + 63) / 64, zs = (g.KK + g.kchunk - 1) / g.kchunk;
+    int ti, tj, z;
+    if (zs > 1) {
+        const int z8 = gemm_round8(zs);
+        z = local % z8;
+        ti = (local / z8) % gx;
+        tj = local / (z8 * gx);
+    } else {
+        z = 0;
+        tj = (local % (8 * gy)) / 8;
+        ti = (local / (8 * gy)) * 8 + (local & 7);
     }
-    float4 ra[2], rb[2];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            ra[e] = gemm_load4(g.A, g.sai, g.sak, a_k_fast, a_vec, i0 + am[e], k0 + ak[e], g.I, k_hi);
-            rb[e] = gemm_load4(g.B, g.sbn, g.sbk, b_k_fast, b_vec, j0 + bm[e], k0 + bk[e], g.J, k_hi);
-        }
-    };
-    auto stage = [&](float (&S)[64][GBK + 1], bool k_fast, int m, int k, const float4 &v) {
-        if (k_fast) { S[m][k] = v.x; S[m][k + 1] = v.y; S[m][k + 2] = v.z; S[m][k + 3] = v.w; }
-        else { S[m][k] = v.x; S[m + 1][k] = v.y; S[m + 2][k] = v.z; S[m + 3][k] = v.w; }
-    };
-    fetch(k_lo);
-    for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            stage(As, a_k_fast, am[e], ak[e], ra[e]);
-            stage(Bs, b_k_fast, bm[e], bk[e], rb[e]);
-        }
-        __syncthreads();
-        if (k0 + GBK < k_hi) fetch(k0 + GBK);
-#pragma unroll
-        for (int t = 0; t < GBK / 2; ++t) acc = MFMA32(As[wi + q][2 * t + h], Bs[wj + q][2 * t + h], acc);
-        __syncthreads();
-    }
-    const int j = j0 + wj + q;
-    if (j >= g.J) return;
-    const float bias_j = (g.mode == 0 && g.bias) ? g.bias[j] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (i >= g.I) continue;
-        float *c = g.C + (long)i * g.ldc + j;
-        if (g.mode == 0) {
-            float v = acc[r] + bias_j;
-            if (g.relu) v = fmaxf(v, 0.0f);
-            if (g.add) v = g.add[(long)i * g.ldadd + j] + v;
-            *c = v;
-        } else if (g.mode == 1) {
-            *c = *c + acc[r];
-        } else {
-            atomicAdd(c, acc[r]);
-        }
+    if (z >= zs || ti >= gx) return;
+    const int i0 = ti * 64, j0 = tj * 64;
+    const int k_lo = z * g.kchunk, k_len = min(g.KK, k_lo + g.kchunk) - k_lo;
+    const bool ak = g.sak == 1, bk = g.sbk == 1;
+    bool full = i0 + 64 <= g.I && j0 + 64 <= g.J && (k_len % GBK) == 0 && (((ak ? g.sai : g.sak) | (bk ? g.sbn : g.sbk)) & 3) == 0;
+    for (int s = 0; s < g.nseg; ++s) full = full && ((reinterpret_cast<size_t>(g.A[s]) | reinterpret_cast<size_t>(g.B[s])) & 15) == 0;
+    if (ak && bk) {
+        if (full) gemm_tile<true, true, true>(g, i0, j0, z, gemm_lds);
+        else gemm_tile<true, true, false>(g, i0, j0, z, gemm_lds);
+    } else if (ak) {
+        if (full) gemm_tile<true, false, true>(g, i0, j0, z, gemm_lds);
+        else gemm_tile<true, false, false>(g, i0, j0, z, gemm_lds);
+    } else {
+        if (full) gemm_tile<false, false, true>(g, i0, j0, z, gemm_lds);
+        else gemm_tile<false, false, false>(g, i0, j0, z, gemm_lds);
     }
 }
 
+#ifdef GEMM_STAMPS
+static int gemm_launch_seq = 0;
+#endif
 struct GemmLaunch {
     GemmBatch b;
     int blocks = 0;
     GemmLaunch() { b.count = 0; }
     GemmLaunch &add(const GemmArgs &g) {
-        const int zs = (g.KK + g.kchunk - 1) / g.kchunk;
         b.g[b.count] = g;
         b.first[b.count++] = blocks;
-        blocks += ((g.I + 63) / 64) * ((g.J + 63) / 64) * zs;
+        blocks += gemm_blocks(g);
         return *this;
     }
     void run(hipStream_t s) {
         b.first[b.count] = blocks;
-        hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), 0, s, b);
+#ifdef GEMM_STAMPS
+        for (int i = 0; i < b.count; ++i) b.g[i].launch_seq = gemm_launch_seq;
+        ++gemm_launch_seq;
+#endif
+        (void)hipFuncSetAttribute((const void *)gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), GEMM_LDS_BYTES, s, b);
     }
 };
+#ifdef GEMM_STAMPS
+extern "C" __attribute__((visibility("default"))) int dgl_debug_gemm_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_stamp_buf), sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 8);
+}
+extern "C" __attribute__((visibility("default"))) int dgl_debug_gemm_stamps_clear() {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(gemm_stamp_buf)) != hipSuccess) return 1;
+    gemm_launch_seq = 0;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 8);
+}
+#endif
+static GemmArgs gemm_args(const float *A, const float *amax_a, const float *B, const float *amax_b, float *C, float *amax_c) {
+    GemmArgs g{};
+    g.A[0] = A; g.B[0] = B; g.amax_a[0] = amax_a; g.amax_b = amax_b; g.nseg = 1; g.C = C; g.amax_c = amax_c;
+    return g;
+}
 // Y[M][N] = X[M][K] W[N][K]^T + b (ReLU) (+ add)
-static GemmArgs linear_fwd(const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N, int K,
-                           bool relu, const float *add, int ldadd) {
-    return GemmArgs{X, W, Y, b, add, M, N, K, ldx, 1, 1, K, ldy, ldadd, 0, relu ? 1 : 0, K};
+static GemmArgs linear_fwd(const float *X, const float *amax_x, int ldx, const float *W, const float *b, float *Y, float *amax_y,
+                           int ldy, int M, int N, int K, bool relu, const float *add, int ldadd) {
+    GemmArgs g = gemm_args(X, amax_x, W, nullptr, Y, amax_y);
+    g.bias = b; g.add = add; g.I = M; g.J = N; g.KK = K; g.sai = ldx; g.sak = 1; g.sbk = 1; g.sbn = K; g.ldc = ldy;
+    g.ldadd = ldadd; g.mode = 0; g.relu = relu ? 1 : 0; g.kchunk = K;
+    return g;
 }
-// dX[M][K] (+)= dY[M][N] W[N][K]; mode 0 store, 1 add in place (no other writer of dX in flight), 2 atomic add
-static GemmArgs linear_bwd_x(const float *dY, int ldy, const float *W, float *dX, int ldx, int M, int N, int K, int mode) {
-    return GemmArgs{dY, W, dX, nullptr, nullptr, M, K, N, ldy, 1, K, 1, ldx, 0, mode, 0, N};
+// dX[M][K] (+)= dY[M][N] W[N][K]; mode 0 store, 1 add in place (no other writer of dX in flight)
+static GemmArgs linear_bwd_x(const float *dY, const float *amax_dy, int ldy, const float *W, float *dX, float *amax_dx, int ldx,
+                             int M, int N, int K, int mode) {
+    GemmArgs g = gemm_args(dY, amax_dy, W, nullptr, dX, amax_dx);
+    g.I = M; g.J = K; g.KK = N; g.sai = ldy; g.sak = 1; g.sbk = K; g.sbn = 1; g.ldc = ldx; g.mode = mode; g.kchunk = N;
+    return g;
 }
-// dW[N][K] += dY[M][N]^T X[M][K]   (atomics over chunks of M)
-static GemmArgs linear_bwd_w(const float *dY, int ldy, const float *X, int ldx, float *dW, int M, int N, int K) {
-    return GemmArgs{dY, X, dW, nullptr, nullptr, N, K, M, 1, ldy, ldx, 1, K, 0, 2, 0, 512};
+// partial products of dW[N][K] = dY[M][N]^T X[M][K] over chunks of 512 rows of M: chunk z goes to part + z N K, and
+// the chunk's term of db[N] = sum over rows of dY to bias_part + z N (when given)
+#define DW_CHUNK 512
+static GemmArgs linear_bwd_w(const float *dY, const float *amax_dy, long row_stride_dy, const float *X, const float *amax_x,
+                             long row_stride_x, float *part, float *bias_part, int M, int N, int K) {
+    GemmArgs g = gemm_args(dY, amax_dy, X, amax_x, part, nullptr);
+    g.colsum_part = bias_part;
+    g.I = N; g.J = K; g.KK = M; g.sai = 1; g.sak = row_stride_dy; g.sbk = row_stride_x; g.sbn = 1; g.ldc = K; g.mode = 3;
+    g.kchunk = DW_CHUNK; g.part_stride = (long)N * K;
+    return g;
 }
 
-// db[j] += sum_i dY[i][j]: a workgroup sums 32 rows (thread = column, 4 row groups of 8, LDS reduction)
-__global__ __launch_bounds__(512) void colsum_kernel(const float *__restrict__ dY, int ld, int M, int N, float *__restrict__ db) {
-    __shared__ float part[4][128];
-    const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
-    const int j = blockIdx.x * 128 + c;
-    const int i_lo = blockIdx.y * 32 + grp * 8, i_hi = min(M, i_lo + 8);
+// dst[e] += part[0][e] + part[1][e] + ... (in that order), e < count, rows `stride` floats apart: the ordered sum of the
+// partial products / partial column sums.  Several sums share one launch (block ranges as in gemm_kernel).
+#define REDUCE_BATCH_MAX 16
+struct ReduceItem {
+    const float *part;
+    float *dst;
+    int Z;
+    long count, stride;
+};
+struct ReduceBatch {
+    ReduceItem it[REDUCE_BATCH_MAX];
+    int first[REDUCE_BATCH_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceBatch batch) {
+    // 32 elements per workgroup, 8 threads per element: thread (element, slice) adds the parts of its slice of Z in
+    // order, four loads in flight, and the eight slice sums are added as a fixed tree
+    __shared__ float red[8][32];
+    int b = 0;
+    while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
+    const ReduceItem &it = batch.it[b];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long e = (long)(blockIdx.x - batch.first[b]) * 32 + el;
+    const int per = (it.Z + 7) / 8, z_lo = sl * per, z_hi = min(it.Z, z_lo + per);
     float s = 0.0f;
-    if (j < N)
-        for (int i = i_lo; i < i_hi; ++i) s += dY[(long)i * ld + j];
-    part[grp][c] = s;
+    if (e < it.count) {
+        const float *p = it.part + e;
+        int z = z_lo;
+        for (; z + 4 <= z_hi; z += 4) {
+            const float a = p[(long)z * it.stride], b2 = p[(long)(z + 1) * it.stride], c = p[(long)(z + 2) * it.stride],
+                        d = p[(long)(z + 3) * it.stride];
+            s += a; s += b2; s += c; s += d;
+        }
+        for (; z < z_hi; ++z) s += p[(long)z * it.stride];
+    }
+    red[sl][el] = s;
     __syncthreads();
-    if (grp == 0 && j < N) atomicAdd(db + j, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+    if (sl == 0 && e < it.count)
+        it.dst[e] += ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
-static void bias_bwd(hipStream_t s, const float *dY, int ld, int M, int N, float *db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(512), 0, s, dY, ld, M, N, db);
-}
-
-// dH *= (H > 0)
-__global__ void relu_bwd_kernel(float *__restrict__ dH, const float *__restrict__ H, long n) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dH[i] = H[i] > 0.0f ? dH[i] : 0.0f;
-}
+struct ReduceLaunch {
+    ReduceBatch b;
+    int blocks = 0;
+    ReduceLaunch() { b.count = 0; }
+    ReduceLaunch &add(const float *part, float *dst, int Z, long count, long stride) {
+        b.it[b.count] = ReduceItem{part, dst, Z, count, stride};
+        b.first[b.count++] = blocks;
+        blocks += (int)((count + 31) / 32);
+        return *this;
+    }
+    void run(hipStream_t s) {
+        if (b.count == 0) return;
+        b.first[b.count] = blocks;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, b);
+    }
+};
 
 // compact copy of the live tokens: T[r*n + t][0..11] = tile[r][t][0..11]
 __global__ void gather_tile_kernel(const float *__restrict__ tile, int row_stride, int R, int n, float *__restrict__ T) {
@@ -237,7 +517,7 @@ __device__ __forceinline__ void stage_head(const float *__restrict__ src, long t
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
                                                        const float *__restrict__ V, int n, float *__restrict__ stats,
-                                                       float *__restrict__ O) {
+                                                       float *__restrict__ O, float *__restrict__ amax_o) {
     extern __shared__ float sm[];              // K[n][16], V[n][16]
     float *Ks = sm, *Vs = sm + n * HDIM;
     const int r = blockIdx.x, hd = blockIdx.y, i = threadIdx.x;
@@ -245,10 +525,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__
     stage_head(K, tok0, n, hd, Ks);
     stage_head(V, tok0, n, hd, Vs);
     __syncthreads();
-    if (i >= n) return;
+    const bool live = i < n;
     float q[HDIM];
 #pragma unroll
-    for (int d = 0; d < HDIM; ++d) q[d] = Q[(tok0 + i) * D_MODEL + hd * HDIM + d];
+    for (int d = 0; d < HDIM; ++d) q[d] = live ? Q[(tok0 + i) * D_MODEL + hd * HDIM + d] : 0.0f;
     // One pass over the keys with a running maximum: whenever it grows, the sum and the output accumulated so
     // far are rescaled (exp(old - new) <= 1).  Equal to softmax(s) V up to rounding.
     float mx = -INFINITY, sum = 0.0f;
@@ -269,11 +549,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__
         axpy16(o, p, Vs + j * HDIM);
     }
     const float inv = 1.0f / sum;
+    float omax = 0.0f;
+    if (live) {
 #pragma unroll
-    for (int d = 0; d < HDIM; ++d) O[(tok0 + i) * D_MODEL + hd * HDIM + d] = o[d] * inv;
-    float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
-    st[0] = mx;
-    st[1] = sum;
+        for (int d = 0; d < HDIM; ++d) {
+            const float v = o[d] * inv;
+            O[(tok0 + i) * D_MODEL + hd * HDIM + d] = v;
+            omax = fmaxf(omax, fabsf(v));
+        }
+        float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
+        st[0] = mx;
+        st[1] = sum;
+    }
+    omax = wave_max_f32(omax);
+    if ((threadIdx.x & 63) == 0) atomic_max_abs(amax_o, omax);
 }
 
 // Backward of the above.  dO, O [M][128] -> dQ, dK, dV [M][128].
@@ -283,7 +572,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
                                                        const float *__restrict__ V, const float *__restrict__ O,
                                                        const float *__restrict__ dO, int n,
                                                        const float *__restrict__ stats, float *__restrict__ dQ,
-                                                       float *__restrict__ dK, float *__restrict__ dV) {
+                                                       float *__restrict__ dK, float *__restrict__ dV,
+                                                       float *__restrict__ amax_dqkv) {     // [3]: bounds of |dQ|, |dK|, |dV|
     extern __shared__ float sm[];              // Q, K, V, dO: [n][16] each; row max, 1 / row sum, dO.O: [n] each
     float *Qs = sm, *Ks = Qs + n * HDIM, *Vs = Ks + n * HDIM, *Gs = Vs + n * HDIM;
     float *Mx = Gs + n * HDIM, *Inv = Mx + n, *Dt = Inv + n;
@@ -307,8 +597,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
         Dt[i] = d;
     }
     __syncthreads();
-    if (!live) return;
-    {   // thread = query i
+    float mq = 0.0f, mk = 0.0f, mv = 0.0f;
+    if (live) {   // thread = query i
         float q[HDIM], go[HDIM], a[HDIM];
 #pragma unroll
         for (int d = 0; d < HDIM; ++d) { q[d] = Qs[i * HDIM + d]; go[d] = Gs[i * HDIM + d]; a[d] = 0.0f; }
@@ -319,9 +609,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
             axpy16(a, ds, Ks + j * HDIM);
         }
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) dQ[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
+        for (int d = 0; d < HDIM; ++d) {
+            dQ[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
+            mq = fmaxf(mq, fabsf(a[d]));
+        }
     }
-    {   // thread = key j (= i)
+    if (live) {   // thread = key j (= i)
         float k[HDIM], v[HDIM], ak[HDIM], av[HDIM];
 #pragma unroll
         for (int d = 0; d < HDIM; ++d) { k[d] = Ks[i * HDIM + d]; v[d] = Vs[i * HDIM + d]; ak[d] = 0.0f; av[d] = 0.0f; }
@@ -335,7 +628,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
         for (int d = 0; d < HDIM; ++d) {
             dK[(tok0 + i) * D_MODEL + hd * HDIM + d] = ak[d];
             dV[(tok0 + i) * D_MODEL + hd * HDIM + d] = av[d];
+            mk = fmaxf(mk, fabsf(ak[d]));
+            mv = fmaxf(mv, fabsf(av[d]));
         }
+    }
+    mq = wave_max_f32(mq);
+    mk = wave_max_f32(mk);
+    mv = wave_max_f32(mv);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_abs(amax_dqkv, mq);
+        atomic_max_abs(amax_dqkv + AMAX_STRIDE, mk);
+        atomic_max_abs(amax_dqkv + 2 * AMAX_STRIDE, mv);
     }
 }
 
@@ -344,7 +647,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__
 // of every row replaced by  W_a x_anchor + b_a.  One workgroup per (row, anchor), 128 threads.
 __global__ __launch_bounds__(128) void anchor_fwd_kernel(const float *__restrict__ X, float *__restrict__ Y, int n, int tok0_,
                                                          int tok1_, const float *__restrict__ W0, const float *__restrict__ b0,
-                                                         const float *__restrict__ W1, const float *__restrict__ b1) {
+                                                         const float *__restrict__ W1, const float *__restrict__ b1,
+                                                         float *__restrict__ amax_y) {
     __shared__ float xs[D_MODEL];
     const int r = blockIdx.x, a = blockIdx.y, c = threadIdx.x;
     const long tk = (long)r * n + (a == 0 ? tok0_ : tok1_);
@@ -353,24 +657,28 @@ __global__ __launch_bounds__(128) void anchor_fwd_kernel(const float *__restrict
     __syncthreads();
     float s = 0.0f;
     for (int k = 0; k < D_MODEL; ++k) s = fmaf(W[c * D_MODEL + k], xs[k], s);
-    Y[tk * D_MODEL + c] = s + b[c];
+    s += b[c];
+    Y[tk * D_MODEL + c] = s;
+    s = wave_max_f32(fabsf(s));
+    if ((c & 63) == 0) atomic_max_abs(amax_y, s);
 }
-// dX = dY except at the anchors, where dX_anchor = W_a^T dY_anchor; db_a += dY_anchor
-// (dW_a += dY_anchor x_anchor^T runs before this kernel as a strided GEMM over the rows' anchor tokens)
-__global__ __launch_bounds__(128) void anchor_bwd_kernel(const float *__restrict__ X, float *__restrict__ dY, int n, int tok0_,
-                                                         int tok1_, const float *__restrict__ W0, const float *__restrict__ W1,
-                                                         float *__restrict__ db0, float *__restrict__ db1) {
+// dX = dY except at the anchors, where dX_anchor = W_a^T dY_anchor; row r's term of db_a (= dY_anchor) goes to
+// db_part[a][r][128] (dW_a += dY_anchor x_anchor^T runs before this kernel as a strided GEMM over the rows' anchor tokens)
+__global__ __launch_bounds__(128) void anchor_bwd_kernel(float *__restrict__ dY, int n, int tok0_, int tok1_,
+                                                         const float *__restrict__ W0, const float *__restrict__ W1,
+                                                         float *__restrict__ db_part, float *__restrict__ amax_dx) {
     __shared__ float gs[D_MODEL];
     const int r = blockIdx.x, a = blockIdx.y, c = threadIdx.x;
     const long tk = (long)r * n + (a == 0 ? tok0_ : tok1_);
     const float *W = a == 0 ? W0 : W1;
-    float *db = a == 0 ? db0 : db1;
     gs[c] = dY[tk * D_MODEL + c];
     __syncthreads();
     float s = 0.0f;
     for (int o = 0; o < D_MODEL; ++o) s = fmaf(W[o * D_MODEL + c], gs[o], s);
     dY[tk * D_MODEL + c] = s;                                     // becomes dX in place
-    atomicAdd(db + c, gs[c]);
+    db_part[((long)a * gridDim.x + r) * D_MODEL + c] = gs[c];
+    s = wave_max_f32(fabsf(s));
+    if ((c & 63) == 0) atomic_max_abs(amax_dx, s);
 }
 
 // -------------------------------------------------------------------------- output stage
@@ -382,7 +690,9 @@ __global__ __launch_bounds__(64) void output_kernel(const float *__restrict__ X,
                                                     const float *__restrict__ bf, dgl_policy_io_t io,
                                                     const int32_t *__restrict__ teacher, float grad_scale,
                                                     float *__restrict__ teacher_prob, float *__restrict__ dX,
-                                                    float *__restrict__ dwf, float *__restrict__ dbf) {
+                                                    float *__restrict__ dwf_part,      // [R][128]: row r's term of dwf
+                                                    float *__restrict__ dbf_part,      // [R]
+                                                    float *__restrict__ amax_dx) {
     extern __shared__ float lg[];              // [n] logits, then probabilities
     const int r = blockIdx.x, lane = threadIdx.x, n = io.n;
     const int stride = io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS;
@@ -463,7 +773,8 @@ __global__ __launch_bounds__(64) void output_kernel(const float *__restrict__ X,
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dbsum += __shfl_xor(dbsum, o, 64);
-    if (lane == 0 && dbsum != 0.0f) atomicAdd(dbf, dbsum);
+    if (lane == 0) dbf_part[r] = dbsum;
+    float gmax = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (int c = lane; c < D_MODEL; c += 64) {
@@ -472,10 +783,13 @@ __global__ __launch_bounds__(64) void output_kernel(const float *__restrict__ X,
         for (int t = 0; t < n; ++t) {
             const float dl = lg[t];
             dX[((long)r * n + t) * D_MODEL + c] = dl * w;
+            gmax = fmaxf(gmax, fabsf(dl * w));
             dw = fmaf(dl, xr[t * D_MODEL + c], dw);
         }
-        if (dw != 0.0f) atomicAdd(dwf + c, dw);
+        dwf_part[(long)r * D_MODEL + c] = dw;
     }
+    gmax = wave_max_f32(gmax);
+    if (lane == 0) atomic_max_abs(amax_dx, gmax);
 }
 
 // --------------------------------------------------------------------------------- Adam
@@ -511,13 +825,36 @@ extern "C" int dgl_adam_step(float *params, const float *grads, float *exp_avg, 
 
 // ----------------------------------------------------------------------- orchestration
 // Workspace (floats), M = R*n tokens:
-//   T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | E [M][128] (encoder output before the
-//   anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row statistics [R][8][n][2]
-//   | backward scratch: dA dB dQ dK dV [M][128] each, dH [M][512]
+//   magnitude bounds [64][16 parts, 128 bytes apart] | T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | E [M][128] (encoder
+//   output before the anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row
+//   statistics [R][8][n][2] | backward scratch: dA dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
+//   block's weight and bias gradients
+#define AMAX_SLOTS 64
+#define AMAX_FLOATS (AMAX_SLOTS * AMAX_STRIDE)
+enum {
+    AX_X = 0,        // +l, l = 0..4 (X[1]'s slot also bounds E)
+    AX_AO = 5,       // +l
+    AX_O1 = 9,       // +l
+    AX_H = 13,       // +l
+    AX_DX = 17,      // +l, l = 0..4: gradient with respect to X[l]
+    AX_DMID = 22,    // +l: gradient with respect to O1[l]
+    AX_DB = 26,      // +l: gradient with respect to AO[l]
+    AX_DQKV = 30,    // +3l: dQ, dK, dV of block l
+    AX_DH = 42,      // +l
+};
+static size_t part_floats(int R, int n) {
+    const size_t M = (size_t)R * n;
+    const size_t zm = (M + DW_CHUNK - 1) / DW_CHUNK, zr = ((size_t)R + DW_CHUNK - 1) / DW_CHUNK;
+    // one block: dW2, dW1 (128x512 each), dWc, dWq, dWk, dWv (128x128 each), db2, dbc (128), db1 (512); with it at most:
+    // the two anchor layers (dW over rows, db per row), the output stage's per-row terms, the embedding layer
+    return zm * (2 * (size_t)D_MODEL * FF_DIM + 4 * (size_t)D_MODEL * D_MODEL) + zm * (2 * D_MODEL + FF_DIM) +
+           2 * zr * D_MODEL * D_MODEL + 2 * (size_t)R * D_MODEL + (size_t)R * (D_MODEL + 4) + zm * D_MODEL * DGL_TILE_STRIDE +
+           zm * D_MODEL;
+}
 static size_t ws_floats(int R, int n) {
     const size_t M = (size_t)R * n;
     const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * 2;
-    return M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM;
+    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM + part_floats(R, n);
 }
 extern "C" int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n) { return (int64_t)ws_floats(R, n); }
 
@@ -537,16 +874,39 @@ static int check_general(const dgl_policy_weights_t *w, const dgl_policy_io_t *i
     return DGL_OK;
 }
 
+// Partial sums of one stage of the backward pass: space handed out from the workspace's last region, the ordered
+// sums queued, everything added to the gradient buffers by one launch at the end of the stage.
+struct PartialSums {
+    float *base, *next, *end;
+    ReduceLaunch red;
+    PartialSums(float *b, size_t floats) : base(b), next(b), end(b + floats) {}
+    // space for Z parts of `count` floats, to be summed into dst
+    float *take(float *dst, int Z, long count) {
+        float *p = next;
+        next += (size_t)Z * count;
+        red.add(p, dst, Z, count, count);
+        return p;
+    }
+    bool fits() const { return next <= end && red.b.count <= REDUCE_BATCH_MAX; }
+    void flush(hipStream_t s) {
+        red.run(s);
+        red = ReduceLaunch();
+        next = base;
+    }
+};
 extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
                                   const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale, float *ws,
                                   float *teacher_prob_out, dgl_stream_t stream) {
     if (int e = check_general(w, io, ws)) return e;
     DGL_CHECK_ARG(grad == nullptr || teacher != nullptr, "gradients need the teacher's actions");
+    DGL_CHECK_ARG((reinterpret_cast<size_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int R = io->R, n = io->n, F = io->problem == DGL_PROBLEM_TSP ? 7 : 9;
     const int M = R * n;
     const size_t MD = (size_t)M * D_MODEL, MF = (size_t)M * FF_DIM, PP = (size_t)R * HEADS * n * 2;
-    float *T = ws;
+    float *ax = ws;
+    auto bound = [ax](int t) { return ax + (size_t)t * AMAX_STRIDE; };      // the t-th magnitude bound
+    float *T = ws + AMAX_FLOATS;
     float *X[5];
     float *p = T + (size_t)M * DGL_TILE_STRIDE;
     for (int l = 0; l < 5; ++l) { X[l] = p; p += MD; }
@@ -562,6 +922,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     float *dK = p; p += MD;
     float *dV = p; p += MD;
     float *dH = p; p += MF;
+    PartialSums ps(p, part_floats(R, n));
     const int anchor0 = io->k_last, anchor1 = n - 1;
     const bool cvrp = io->problem == DGL_PROBLEM_CVRP;
     const int n_anchor = cvrp ? 2 : 1;
@@ -570,87 +931,125 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
 
     // ---- forward
+    (void)hipMemsetAsync(ax, 0, AMAX_FLOATS * sizeof(float), s);
     hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
                        io->tile_row_stride, R, n, T);
-    GemmLaunch().add(linear_fwd(T, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], D_MODEL, M, D_MODEL, F, false, nullptr, 0)).run(s);
+    GemmLaunch()
+        .add(linear_fwd(T, nullptr, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], bound(AX_X), D_MODEL, M, D_MODEL, F, false, nullptr, 0))
+        .run(s);
     for (int l = 0; l < 4; ++l) {
         const dgl_block_weights_t &k = w->block[l];
-        const float *Xin = X[l];
+        const float *Xin = X[l], *ax_in = bound(AX_X + l);
         if (l == 1) {
             // E keeps the encoder output; X[1] = E with re-embedded anchors
             (void)hipMemcpyAsync(E, X[1], MD * sizeof(float), hipMemcpyDeviceToDevice, s);
             hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, X[1], n, anchor0, anchor1,
-                               w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0]);
+                               w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0], bound(AX_X + 1));
         }
         GemmLaunch()
-            .add(linear_fwd(Xin, D_MODEL, k.wq, nullptr, Qb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, D_MODEL, k.wk, nullptr, Kb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, D_MODEL, k.wv, nullptr, Vb[l], D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wq, nullptr, Qb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wk, nullptr, Kb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wv, nullptr, Vb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
             .run(s);
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(256), attn_lds, s, Qb[l], Kb[l], Vb[l], n, P[l], AO[l]);
-        GemmLaunch().add(linear_fwd(AO[l], D_MODEL, k.wc, k.bc, O1[l], D_MODEL, M, D_MODEL, D_MODEL, false, Xin, D_MODEL)).run(s);
-        GemmLaunch().add(linear_fwd(O1[l], D_MODEL, k.w1, k.b1, H[l], FF_DIM, M, FF_DIM, D_MODEL, true, nullptr, 0)).run(s);
-        GemmLaunch().add(linear_fwd(H[l], FF_DIM, k.w2, k.b2, X[l + 1], D_MODEL, M, D_MODEL, FF_DIM, false, O1[l], D_MODEL)).run(s);
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(256), attn_lds, s, Qb[l], Kb[l], Vb[l], n, P[l], AO[l], bound(AX_AO + l));
+        GemmLaunch()
+            .add(linear_fwd(AO[l], bound(AX_AO + l), D_MODEL, k.wc, k.bc, O1[l], bound(AX_O1 + l), D_MODEL, M, D_MODEL, D_MODEL, false, Xin,
+                            D_MODEL))
+            .run(s);
+        GemmLaunch()
+            .add(linear_fwd(O1[l], bound(AX_O1 + l), D_MODEL, k.w1, k.b1, H[l], bound(AX_H + l), FF_DIM, M, FF_DIM, D_MODEL, true, nullptr, 0))
+            .run(s);
+        GemmLaunch()
+            .add(linear_fwd(H[l], bound(AX_H + l), FF_DIM, k.w2, k.b2, X[l + 1], bound(AX_X + l + 1), D_MODEL, M, D_MODEL, FF_DIM, false, O1[l],
+                            D_MODEL))
+            .run(s);
     }
     const bool train = grad != nullptr;
+    float *dwf_part = nullptr, *dbf_part = nullptr;
+    if (train) {
+        dwf_part = ps.take((float *)grad->final_w, R, D_MODEL);
+        dbf_part = ps.take((float *)grad->final_b, R, 1);
+    }
     hipLaunchKernelGGL(output_kernel, dim3(R), dim3(64), (size_t)n * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
-                       teacher, grad_scale, teacher_prob_out, train ? dA : nullptr, train ? (float *)grad->final_w : nullptr,
-                       train ? (float *)grad->final_b : nullptr);
+                       teacher, grad_scale, teacher_prob_out, train ? dA : nullptr, dwf_part, dbf_part, bound(AX_DX + 4));
     DGL_CHECK_LAUNCH("dgl_policy_general (forward)");
     if (!train) return DGL_OK;
 
     // ---- backward: dA holds the gradient of the current block's output
+    const int zm = (M + DW_CHUNK - 1) / DW_CHUNK, zr = (R + DW_CHUNK - 1) / DW_CHUNK;
     for (int l = 3; l >= 0; --l) {
         const dgl_block_weights_t &k = w->block[l];
         const dgl_block_weights_t &g = grad->block[l];
         const float *Xin = X[l];
-        // Products that share no output run in one launch each.
-        // X[l+1] = O1 + W2 H + b2
-        bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)g.b2);
+        const float *ax_out = bound(AX_DX + l + 1), *ax_h = bound(AX_DH + l), *ax_q = bound(AX_DQKV + 3 * l);
+        float *ax_mid = bound(AX_DMID + l);
+        // Products that share no output run in one launch each; the weight-gradient product also sums its dY operand
+        // over the tokens (the bias gradient).
+        // X[l+1] = O1 + W2 H + b2;  H = relu(..): dH = (dA W2) where H > 0
+        GemmArgs dh = linear_bwd_x(dA, ax_out, D_MODEL, k.w2, dH, bound(AX_DH + l), FF_DIM, M, D_MODEL, FF_DIM, 0);
+        dh.gate = H[l];
+        float *b2_part = ps.take((float *)g.b2, zm, D_MODEL);
         GemmLaunch()
-            .add(linear_bwd_w(dA, D_MODEL, H[l], FF_DIM, (float *)g.w2, M, D_MODEL, FF_DIM))
-            .add(linear_bwd_x(dA, D_MODEL, k.w2, dH, FF_DIM, M, D_MODEL, FF_DIM, 0))
+            .add(linear_bwd_w(dA, ax_out, D_MODEL, H[l], bound(AX_H + l), FF_DIM, ps.take((float *)g.w2, zm, D_MODEL * FF_DIM), b2_part, M,
+                              D_MODEL, FF_DIM))
+            .add(dh)
             .run(s);
-        hipLaunchKernelGGL(relu_bwd_kernel, dim3(2048), dim3(256), 0, s, dH, H[l], (long)MF);
         // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1   (accumulated into dA)
-        bias_bwd(s, dH, FF_DIM, M, FF_DIM, (float *)g.b1);
+        float *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
         GemmLaunch()
-            .add(linear_bwd_w(dH, FF_DIM, O1[l], D_MODEL, (float *)g.w1, M, FF_DIM, D_MODEL))
-            .add(linear_bwd_x(dH, FF_DIM, k.w1, dA, D_MODEL, M, FF_DIM, D_MODEL, 1))
+            .add(linear_bwd_w(dH, ax_h, FF_DIM, O1[l], bound(AX_O1 + l), D_MODEL, ps.take((float *)g.w1, zm, FF_DIM * D_MODEL), b1_part, M,
+                              FF_DIM, D_MODEL))
+            .add(linear_bwd_x(dH, ax_h, FF_DIM, k.w1, dA, ax_mid, D_MODEL, M, FF_DIM, D_MODEL, 1))
             .run(s);
         // O1 = Xin + Wc AO + bc
-        bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)g.bc);
+        float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
         GemmLaunch()
-            .add(linear_bwd_w(dA, D_MODEL, AO[l], D_MODEL, (float *)g.wc, M, D_MODEL, D_MODEL))
-            .add(linear_bwd_x(dA, D_MODEL, k.wc, dB, D_MODEL, M, D_MODEL, D_MODEL, 0))       // dB = dAO
+            .add(linear_bwd_w(dA, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
+                              D_MODEL, D_MODEL))
+            .add(linear_bwd_x(dA, ax_mid, D_MODEL, k.wc, dB, bound(AX_DB + l), D_MODEL, M, D_MODEL, D_MODEL, 0))       // dB = dAO
             .run(s);
         hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS), dim3(256), attn_bwd_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n, P[l], dQ,
-                           dK, dV);
-        // dXin = dA + dQ Wq + dK Wk + dV Wv: three products into one output, added atomically
+                           dK, dV, bound(AX_DQKV + 3 * l));
+        // dXin = dA + dQ Wq + dK Wk + dV Wv: the three products accumulate in one tile, added to dA in place
+        GemmArgs dx = linear_bwd_x(dQ, ax_q, D_MODEL, k.wq, dA, bound(AX_DX + l), D_MODEL, M, D_MODEL, D_MODEL, 0);
+        dx.A[1] = dK; dx.B[1] = k.wk; dx.amax_a[1] = ax_q + AMAX_STRIDE;
+        dx.A[2] = dV; dx.B[2] = k.wv; dx.amax_a[2] = ax_q + 2 * AMAX_STRIDE;
+        dx.nseg = 3;
+        dx.add = dA; dx.ldadd = D_MODEL;
         GemmLaunch()
-            .add(linear_bwd_w(dQ, D_MODEL, Xin, D_MODEL, (float *)g.wq, M, D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dK, D_MODEL, Xin, D_MODEL, (float *)g.wk, M, D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dV, D_MODEL, Xin, D_MODEL, (float *)g.wv, M, D_MODEL, D_MODEL))
-            .add(linear_bwd_x(dQ, D_MODEL, k.wq, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
-            .add(linear_bwd_x(dK, D_MODEL, k.wk, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
-            .add(linear_bwd_x(dV, D_MODEL, k.wv, dA, D_MODEL, M, D_MODEL, D_MODEL, 2))
+            .add(linear_bwd_w(dQ, ax_q, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wq, zm, D_MODEL * D_MODEL), nullptr, M,
+                              D_MODEL, D_MODEL))
+            .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL), nullptr, M,
+                              D_MODEL, D_MODEL))
+            .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL), nullptr, M,
+                              D_MODEL, D_MODEL))
+            .add(dx)
             .run(s);
         if (l == 1) {
             // dW_a[c][k] += sum_r dA[anchor of row r][c] E[anchor of row r][k]: the rows' anchor tokens are n tokens apart
             GemmLaunch gl;
             for (int a = 0; a < n_anchor; ++a) {
                 const long off = (long)(a == 0 ? anchor0 : anchor1) * D_MODEL;
-                gl.add(GemmArgs{dA + off, E + off, (float *)grad->anchor_w[a], nullptr, nullptr, D_MODEL, D_MODEL, R, 1,
-                                (long)n * D_MODEL, (long)n * D_MODEL, 1, D_MODEL, 0, 2, 0, 512});
+                gl.add(linear_bwd_w(dA + off, bound(AX_DX + 1), (long)n * D_MODEL, E + off, bound(AX_X + 1), (long)n * D_MODEL,
+                                    ps.take((float *)grad->anchor_w[a], zr, D_MODEL * D_MODEL), nullptr, R, D_MODEL, D_MODEL));
             }
             gl.run(s);
-            hipLaunchKernelGGL(anchor_bwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, dA, n, anchor0, anchor1, w->anchor_w[0],
-                               w->anchor_w[cvrp ? 1 : 0], (float *)grad->anchor_b[0], (float *)grad->anchor_b[cvrp ? 1 : 0]);
+            float *db_part = ps.next;
+            for (int a = 0; a < n_anchor; ++a) ps.take((float *)grad->anchor_b[a], R, D_MODEL);
+            hipLaunchKernelGGL(anchor_bwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, dA, n, anchor0, anchor1, w->anchor_w[0],
+                               w->anchor_w[cvrp ? 1 : 0], db_part, bound(AX_DX + 1));
         }
+        if (l == 0) {
+            // X[0] = T We^T + be
+            float *be_part = ps.take((float *)grad->emb_b, zm, D_MODEL);
+            GemmLaunch()
+                .add(linear_bwd_w(dA, bound(AX_DX), D_MODEL, T, nullptr, DGL_TILE_STRIDE, ps.take((float *)grad->emb_w, zm, D_MODEL * F),
+                                  be_part, M, D_MODEL, F))
+                .run(s);
+        }
+        if (!ps.fits()) return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "partial-sum region of the workspace too small (internal)");
+        ps.flush(s);
     }
-    // X[0] = T We^T + be
-    GemmLaunch().add(linear_bwd_w(dA, D_MODEL, T, DGL_TILE_STRIDE, (float *)grad->emb_w, M, D_MODEL, F)).run(s);
-    bias_bwd(s, dA, D_MODEL, M, D_MODEL, (float *)grad->emb_b);
     DGL_CHECK_LAUNCH("dgl_policy_general (backward)");
     return DGL_OK;
 }
@@ -662,9 +1061,10 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
 // until the process ends; the host learns that address once per device (hipGetSymbolAddress with the
 // device current) and hands it to the kernels exactly as dgl_policy_general hands them `ws`.  The
 // array's name itself is never passed to a kernel or a copy from host code.
-// All calls on one device share the array: calls that overlap in time on one device race.  Nothing
-// in the workspace has to start at zero (every buffer is written in full before it is read), so the
-// previous call's contents are simply overwritten.
+// All calls on one device share the array: calls that overlap in time on one device race.  The only
+// part of the workspace that has to start at zero, the magnitude bounds at its head, is cleared by
+// every call; every other buffer is written in full before it is read, so the previous call's
+// contents are simply overwritten.
 static __device__ __align__(256) float scratch[DGL_STATIC_WORKSPACE_FLOATS];
 
 #define DGL_MAX_DEVICES 64

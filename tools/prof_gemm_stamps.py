@@ -1,0 +1,44 @@
+"""Phase timing inside the training path's GEMM workgroups (library built with -DGEMM_STAMPS:
+tools/build_variant.sh stamps wt -DGEMM_STAMPS; run with DGL_AMD_LIB=dgl_amd/lib/libdgl_amd_stamps.so)."""
+import ctypes, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from dgl_amd import _lib
+from dgl_amd._lib import PROBLEM_CVRP
+from dgl_amd.engine import CvrpEngine
+from dgl_amd.train import PolicyTrainer
+from dgl_amd.weights import random_state_dict
+R, N, k = 64, 1000, 100
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(0)
+xy = torch.rand(R, N + 1, 2, generator=g).to(dev)
+dem = torch.cat((torch.zeros(R, 1), torch.randint(1, 200, (R, N), generator=g) / 500.0), 1).to(dev)
+eng = CvrpEngine(xy, dem, 1, k, k, demand_in_distance=True)
+tr = PolicyTrainer(random_state_dict('CVRP', 1), PROBLEM_CVRP, dev)
+eng.reset()
+eng.step(torch.full((R,), 5 + N + 1, dtype=torch.int32, device=dev))
+teacher = eng.idx_last[:, 0].clone()
+for _ in range(3):
+    tr.zero_grad(); tr.forward_backward(eng, teacher); tr.optimizer_step()
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.dgl_debug_gemm_stamps_clear.restype = ctypes.c_int
+assert lib.dgl_debug_gemm_stamps_clear() == 0
+tr.zero_grad(); tr.forward_backward(eng, teacher); tr.optimizer_step()
+torch.cuda.synchronize()
+WGS = 4096
+buf = np.zeros(64 * WGS * 8, dtype=np.uint64)
+lib.dgl_debug_gemm_stamps.restype = ctypes.c_int
+assert lib.dgl_debug_gemm_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+buf = buf.reshape(64, WGS, 8).astype(np.int64)
+names = ["start", "loads+stage0", "barrier", "rest of K", "epilogue", "amax"]
+for L in range(64):
+    b = buf[L]
+    live = (b[:, 0] > 0) & (b[:, 6] > b[:, 0])
+    if not live.any():
+        continue
+    s = b[live]
+    t0 = s[:, 0].min()
+    d = np.diff(s[:, :7], axis=1)
+    print(f"launch slot {L}: {live.sum()} live workgroups, span {s[:, 6].max() - t0} ticks; start spread {np.percentile(s[:, 0] - t0, [50, 90, 100]).astype(int)}; "
+          f"per-workgroup total median {np.median(s[:, 6] - s[:, 0]):.0f}")
+    print("    " + "  ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names)))
