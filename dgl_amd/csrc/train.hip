@@ -107,11 +107,11 @@ __device__ __forceinline__ float4 gemm_load4(const float *__restrict__ P, long s
 // tile; dgl_debug_gemm_stamps copies the records of the last 64 launches out.
 #ifdef GEMM_STAMPS
 #define GEMM_STAMP_WGS 4096
-static __device__ unsigned long long gemm_stamp_buf[64 * GEMM_STAMP_WGS * 8];
+static __device__ unsigned long long gemm_stamp_buf[64 * GEMM_STAMP_WGS * 16];
 #define GSTAMP(i)                                                                                                           \
     do {                                                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < GEMM_STAMP_WGS)                                                                \
-            gemm_stamp_buf[((size_t)(g.launch_seq & 63) * GEMM_STAMP_WGS + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+            gemm_stamp_buf[((size_t)(g.launch_seq & 63) * GEMM_STAMP_WGS + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define GSTAMP(i)
@@ -188,6 +188,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
             GSTAMP(1);
         }
         for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
+#ifdef GEMM_STAMPS
+            const bool st2 = seg == 0 && k0 == k_lo + GBK;     // the second stage, phase by phase
+            if (st2) { GSTAMP(8); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(9); }
+#endif
             if (FULL) {
                 if (want_csum) {
 #pragma unroll
@@ -216,9 +220,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
                 }
             }
             if (k0 == k_lo && seg == 0) GSTAMP(2);
+#ifdef GEMM_STAMPS
+            if (st2) GSTAMP(10);
+#endif
             __syncthreads();
             if (k0 == k_lo && seg == 0) GSTAMP(3);
+#ifdef GEMM_STAMPS
+            if (st2) GSTAMP(11);
+#endif
             if (FULL && k0 + GBK < k_hi) fetch(k0 + GBK);
+#ifdef GEMM_STAMPS
+            if (st2) GSTAMP(12);
+#endif
             const int ksteps = FULL ? GBK / 16 : (min(GBK, k_hi - k0) + 15) / 16;
 #pragma unroll 2
             for (int t = 0; t < ksteps; ++t) {
@@ -229,7 +242,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
                 acc = MFMA16(ah, bl, acc);
                 acc = MFMA16(ah, bh, acc);
             }
+#ifdef GEMM_STAMPS
+            if (st2) GSTAMP(13);
+#endif
             __syncthreads();
+#ifdef GEMM_STAMPS
+            if (st2) GSTAMP(14);
+#endif
         }
     }
     GSTAMP(4);
@@ -324,6 +343,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
         ti = (local / (8 * gy)) * 8 + (local & 7);
     }
     if (z >= zs || ti >= gx) return;
+#ifdef GEMM_SAME_TILE
+    ti = tj = z = 0;                                         // (timing experiment: every workgroup works on one cache-resident tile)
+#endif
     const int i0 = ti * 64, j0 = tj * 64;
     const int k_lo = z * g.kchunk, k_len = min(g.KK, k_lo + g.kchunk) - k_lo;
     const bool ak = g.sak == 1, bk = g.sbk == 1;
@@ -366,13 +388,13 @@ struct GemmLaunch {
 };
 #ifdef GEMM_STAMPS
 extern "C" __attribute__((visibility("default"))) int dgl_debug_gemm_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_stamp_buf), sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_stamp_buf), sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 16);
 }
 extern "C" __attribute__((visibility("default"))) int dgl_debug_gemm_stamps_clear() {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(gemm_stamp_buf)) != hipSuccess) return 1;
     gemm_launch_seq = 0;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 8);
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 64 * GEMM_STAMP_WGS * 16);
 }
 #endif
 static GemmArgs gemm_args(const float *A, const float *amax_a, const float *B, const float *amax_b, float *C, float *amax_c) {
@@ -476,170 +498,361 @@ __global__ void gather_tile_kernel(const float *__restrict__ tile, int row_strid
 }
 
 // ---------------------------------------------------------------------------- attention
-// One workgroup per (row, head), n <= 256 tokens, head h = columns 16h..16h+15 of Q, K, V [M][128]
-// (TSP/TSPModel.py:420-441): P[i][j] = softmax_j(q_i.k_j / 4), O_i = sum_j P[i][j] V_j.
-// The n x n probabilities are never stored: every pass recomputes q.k from the head's K (V, Q, dO)
-// rows held in LDS and read as broadcasts; the backward pass gets the row maximum and the row sum
-// of exponentials from the forward pass (stats [R][8][n][2]) and uses
-//     sum_j P[i][j] dP[i][j] = dO_i . O_i.
-__device__ __forceinline__ float dot16(const float (&a)[HDIM], const float *__restrict__ b) {
-    const float4 *b4 = reinterpret_cast<const float4 *>(b);
-    float s = 0.0f;
-#pragma unroll
-    for (int v = 0; v < HDIM / 4; ++v) {
-        const float4 t = b4[v];
-        s = fmaf(a[4 * v], t.x, s);
-        s = fmaf(a[4 * v + 1], t.y, s);
-        s = fmaf(a[4 * v + 2], t.z, s);
-        s = fmaf(a[4 * v + 3], t.w, s);
-    }
-    return s;
+// One workgroup per (row, head), n <= 256 tokens in NT = ceil(n / 32) tiles, head h = columns 16h..16h+15 of
+// Q, K, V [M][128] (TSP/TSPModel.py:420-441): P[i][j] = softmax_j(q_i.k_j / 4), O_i = sum_j P[i][j] V_j.
+// The n x n probabilities are never stored: the backward pass recomputes q.k and gets the row maximum and the row
+// sum of exponentials from the forward pass (stats [R][8][n][2]); it uses  sum_j P[i][j] dP[i][j] = dO_i . O_i.
+//
+// All products run on the f16 matrix cores with split operands, as in gemm_kernel.  One wave owns a tile of 32
+// queries (or, for dK and dV, 32 keys) and walks over the tiles of the other index.  A score tile is computed
+// transposed - keys along the rows, the wave's queries along the columns - so that in the accumulator layout of
+// v_mfma_f32_32x32x16 (lane = column, 16 rows per lane) each lane holds scores of ONE query: the softmax
+// statistics are per lane, and the lane's 16 values are, as they stand, two B operands (k = key) of the next
+// product, whose A operand (V^T, K^T, ...) is read from a transposed LDS image at the matching key positions:
+//     accumulator register r of lane (q, h)  <->  row (r & 3) + 8 (r >> 2) + 4 h;
+//     registers 8 s .. 8 s + 7  =  k-slots 0..7 of k-step s  <->  keys 16 s + 4 h + {0..3, 8..11} of the tile.
+// Only 16 of the 32 output rows of those products (the head dimension) are used.
+//
+// LDS images of a [n][16] head slice, as binary16 hi and lo halves of (value * scale), rows >= n zero:
+//   row-major, 16 halfs per row, the two 8-half blocks of a row swapped on every other group of four rows
+//   (conflict-free 16-byte operand reads without padding);
+//   transposed, [16][32 NT + 4] (row stride = 2 banks mod 32: conflict-free 8-byte reads).
+__device__ __forceinline__ int rm_off(int row, int blk) { return row * 16 + ((blk ^ ((row >> 2) & 1)) << 3); }
+#define ATT_TS(NT) (32 * (NT) + 4)
+
+// exp(x) for x <= 0 with the rounding error of x * log2(e) compensated (v_exp_f32 alone would lose |x| * 1e-7)
+__device__ __forceinline__ float exp_neg(float x) {
+    if (!(x > -100.0f)) return 0.0f;
+    const float L2E = 1.44269502f, L2E_LO = 1.92596299e-8f;
+    const float t = x * L2E;
+    const float lo = fmaf(x, L2E, -t) + x * L2E_LO;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, lo * 0.693147182f, e);
 }
-__device__ __forceinline__ void axpy16(float (&acc)[HDIM], float a, const float *__restrict__ b) {
-    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+// stages head hd of src rows tok0 .. tok0 + n - 1 (times scale) into the images that are given (else nullptr)
+__device__ __forceinline__ void stage_head_split(const float *__restrict__ src, long tok0, int n, int n_pad, int hd, float scale,
+                                                 _Float16 *rm_hi, _Float16 *rm_lo, _Float16 *t_hi, _Float16 *t_lo, int TS) {
+    // item = (pair of tokens 2p, 2p + 1; 8-column block): the transposed image takes the pair as one packed word
+    for (int item = threadIdx.x; item < n_pad; item += blockDim.x) {
+        const int t0 = (item >> 1) * 2, blk = item & 1;
+        float a[8], b[8];
+        const float *pa = src + (tok0 + t0) * D_MODEL + hd * HDIM + 8 * blk;
+        const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float4 a0 = t0 < n ? *reinterpret_cast<const float4 *>(pa) : z4, a1 = t0 < n ? *reinterpret_cast<const float4 *>(pa + 4) : z4;
+        const float4 b0 = t0 + 1 < n ? *reinterpret_cast<const float4 *>(pa + D_MODEL) : z4;
+        const float4 b1 = t0 + 1 < n ? *reinterpret_cast<const float4 *>(pa + D_MODEL + 4) : z4;
+        a[0] = a0.x * scale; a[1] = a0.y * scale; a[2] = a0.z * scale; a[3] = a0.w * scale;
+        a[4] = a1.x * scale; a[5] = a1.y * scale; a[6] = a1.z * scale; a[7] = a1.w * scale;
+        b[0] = b0.x * scale; b[1] = b0.y * scale; b[2] = b0.z * scale; b[3] = b0.w * scale;
+        b[4] = b1.x * scale; b[5] = b1.y * scale; b[6] = b1.z * scale; b[7] = b1.w * scale;
+        if (rm_hi) {
+            u32x4 ah, al, bh, bl;
 #pragma unroll
-    for (int v = 0; v < HDIM / 4; ++v) {
-        const float4 t = b4[v];
-        acc[4 * v] = fmaf(a, t.x, acc[4 * v]);
-        acc[4 * v + 1] = fmaf(a, t.y, acc[4 * v + 1]);
-        acc[4 * v + 2] = fmaf(a, t.z, acc[4 * v + 2]);
-        acc[4 * v + 3] = fmaf(a, t.w, acc[4 * v + 3]);
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, lo;
+                split2(a[2 * e], a[2 * e + 1], hi, lo); ah[e] = hi; al[e] = lo;
+                split2(b[2 * e], b[2 * e + 1], hi, lo); bh[e] = hi; bl[e] = lo;
+            }
+            *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0, blk)) = ah;
+            *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0, blk)) = al;
+            *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0 + 1, blk)) = bh;
+            *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0 + 1, blk)) = bl;
+        }
+        if (t_hi) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned hi, lo;
+                split2(a[e], b[e], hi, lo);
+                *reinterpret_cast<unsigned *>(t_hi + (8 * blk + e) * TS + t0) = hi;
+                *reinterpret_cast<unsigned *>(t_lo + (8 * blk + e) * TS + t0) = lo;
+            }
+        }
     }
 }
-// copies the head's 16 columns of `src` rows tok0..tok0+n-1 into dst[n][16]
-__device__ __forceinline__ void stage_head(const float *__restrict__ src, long tok0, int n, int hd, float *dst) {
-    for (int e = threadIdx.x; e < n * (HDIM / 4); e += blockDim.x) {
-        const int t = e / (HDIM / 4), v = e % (HDIM / 4);
-        reinterpret_cast<float4 *>(dst)[e] =
-            *reinterpret_cast<const float4 *>(src + (tok0 + t) * D_MODEL + hd * HDIM + 4 * v);
+// the wave's own 32 rows as a B operand (lane (q, h): columns 8h..8h+7 of row tok0 + 32 tile + q), rows >= n zero
+__device__ __forceinline__ void load_own_rows(const float *__restrict__ src, long tok0, int n, int row, int hd, int h, float (&v)[8]) {
+    if (row < n) {
+        const float *p = src + (tok0 + row) * D_MODEL + hd * HDIM + 8 * h;
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
     }
+}
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
+    u32x4 h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned a, b;
+        split2(v[2 * e] * scale, v[2 * e + 1] * scale, a, b);
+        h4[e] = a; l4[e] = b;
+    }
+    hi = as_f16x8(h4); lo = as_f16x8(l4);
+}
+// registers 8 s .. 8 s + 7 of an accumulator tile (times scale) as the B operand of k-step s
+__device__ __forceinline__ void acc_operand(const f32x16 &v, int s, float scale, f16x8 &hi, f16x8 &lo) {
+    u32x4 h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned a, b;
+        split2(v[8 * s + 2 * e] * scale, v[8 * s + 2 * e + 1] * scale, a, b);
+        h4[e] = a; l4[e] = b;
+    }
+    hi = as_f16x8(h4); lo = as_f16x8(l4);
+}
+// A operand of k-step s from a transposed image: row d = lane & 15, positions tile * 32 + 16 s + 4 h + {0..3, 8..11}
+__device__ __forceinline__ f16x8 t_operand(const _Float16 *img, int TS, int d, int tile, int s, int h) {
+    const _Float16 *p = img + d * TS + tile * 32 + 16 * s + 4 * h;
+    const u32x2 a = *reinterpret_cast<const u32x2 *>(p), b = *reinterpret_cast<const u32x2 *>(p + 8);
+    return as_f16x8(u32x4{a[0], a[1], b[0], b[1]});
+}
+// acc += A B with split operands
+__device__ __forceinline__ f32x16 mfma_split(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x16 acc) {
+    acc = MFMA16(al, bh, acc);
+    acc = MFMA16(ah, bl, acc);
+    return MFMA16(ah, bh, acc);
+}
+// rows d = 4h..4h+3 and 8+4h..8+4h+3 of an accumulator (registers 0..7) times scale -> dst[16 hd + d] of the lane's token
+__device__ __forceinline__ float store_head_rows(float *__restrict__ dst, const f32x16 &acc, float scale, int h) {
+    const float4 a = {acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale};
+    const float4 b = {acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale};
+    *reinterpret_cast<float4 *>(dst + 4 * h) = a;
+    *reinterpret_cast<float4 *>(dst + 8 + 4 * h) = b;
+    return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                 fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
-                                                       const float *__restrict__ V, int n, float *__restrict__ stats,
-                                                       float *__restrict__ O, float *__restrict__ amax_o) {
-    extern __shared__ float sm[];              // K[n][16], V[n][16]
-    float *Ks = sm, *Vs = sm + n * HDIM;
-    const int r = blockIdx.x, hd = blockIdx.y, i = threadIdx.x;
+// amax_qkv: the bounds of |Q|, |K|, |V| (AMAX_STRIDE apart).  blockDim = 64 NT.
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+                                                       const float *__restrict__ V, int n, const float *__restrict__ amax_qkv,
+                                                       float *__restrict__ stats, float *__restrict__ O, float *__restrict__ amax_o) {
+    extern __shared__ __align__(16) _Float16 att_lds[];
+    const int NT = blockDim.x >> 6, n_pad = 32 * NT, TS = ATT_TS(NT);
+    _Float16 *Kh = att_lds, *Kl = Kh + n_pad * 16, *VTh = Kl + n_pad * 16, *VTl = VTh + 16 * TS;
+    const int r = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x & 63, it = threadIdx.x >> 6, q = lane & 31, h = lane >> 5;
     const long tok0 = (long)r * n;
-    stage_head(K, tok0, n, hd, Ks);
-    stage_head(V, tok0, n, hd, Vs);
+    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
+                sv = pow2_scale_for(amax_read(amax_qkv + 2 * AMAX_STRIDE));
+    stage_head_split(K, tok0, n, n_pad, hd, sk, Kh, Kl, nullptr, nullptr, TS);
+    stage_head_split(V, tok0, n, n_pad, hd, sv, nullptr, nullptr, VTh, VTl, TS);
+    const int i = 32 * it + q;
+    float qv[8];
+    load_own_rows(Q, tok0, n, i, hd, h, qv);
+    f16x8 qh, ql;
+    split8(qv, sq, qh, ql);
     __syncthreads();
-    const bool live = i < n;
-    float q[HDIM];
-#pragma unroll
-    for (int d = 0; d < HDIM; ++d) q[d] = live ? Q[(tok0 + i) * D_MODEL + hd * HDIM + d] : 0.0f;
-    // One pass over the keys with a running maximum: whenever it grows, the sum and the output accumulated so
+    const float cs = 0.25f / (sq * sk);
+    // one pass over the key tiles with a running maximum: whenever it grows, the sum and the output accumulated so
     // far are rescaled (exp(old - new) <= 1).  Equal to softmax(s) V up to rounding.
     float mx = -INFINITY, sum = 0.0f;
-    float o[HDIM];
+    f32x16 o = zero16();
+    for (int jt = 0; jt < NT; ++jt) {
+        const int ko = rm_off(32 * jt + q, h);
+        f32x16 sc = mfma_split(*reinterpret_cast<const f16x8 *>(Kh + ko), *reinterpret_cast<const f16x8 *>(Kl + ko), qh, ql, zero16());
+        float tmax = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < HDIM; ++d) o[d] = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float sc = dot16(q, Ks + j * HDIM) / 4.0f;
-        if (sc > mx) {
-            const float f = expf(mx - sc);          // 0 on the first key (mx = -inf)
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            sc[e] = j < n ? sc[e] * cs : -INFINITY;
+            tmax = fmaxf(tmax, sc[e]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (tmax > mx) {
+            const float f = exp_neg(mx - tmax);          // 0 on the first tile (mx = -inf)
             sum *= f;
 #pragma unroll
-            for (int d = 0; d < HDIM; ++d) o[d] *= f;
-            mx = sc;
+            for (int e = 0; e < 16; ++e) o[e] *= f;
+            mx = tmax;
         }
-        const float p = expf(sc - mx);
-        sum += p;
-        axpy16(o, p, Vs + j * HDIM);
-    }
-    const float inv = 1.0f / sum;
-    float omax = 0.0f;
-    if (live) {
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) {
-            const float v = o[d] * inv;
-            O[(tok0 + i) * D_MODEL + hd * HDIM + d] = v;
-            omax = fmaxf(omax, fabsf(v));
+        for (int e = 0; e < 16; ++e) {
+            sc[e] = exp_neg(sc[e] - mx);
+            sum += sc[e];
         }
-        float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
-        st[0] = mx;
-        st[1] = sum;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ph, pl;
+            acc_operand(sc, s, 1024.0f, ph, pl);
+            o = mfma_split(t_operand(VTh, TS, q & 15, jt, s, h), t_operand(VTl, TS, q & 15, jt, s, h), ph, pl, o);
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    float omax = 0.0f;
+    if (i < n) {
+        omax = store_head_rows(O + (tok0 + i) * D_MODEL + hd * HDIM, o, 1.0f / (1024.0f * sv * sum), h);
+        if (h == 0) {
+            float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
+            st[0] = mx;
+            st[1] = sum;
+        }
     }
     omax = wave_max_f32(omax);
-    if ((threadIdx.x & 63) == 0) atomic_max_abs(amax_o, omax);
+    if (lane == 0) atomic_max_abs(amax_o, omax);
 }
 
 // Backward of the above.  dO, O [M][128] -> dQ, dK, dV [M][128].
 //   dS[i][j] = P[i][j] (dO_i . V_j - dO_i . O_i) / 4 (gradient with respect to q.k, the 1/4 included)
 //   dQ_i = sum_j dS[i][j] K_j;  dK_j = sum_i dS[i][j] Q_i;  dV_j = sum_i P[i][j] dO_i
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
-                                                       const float *__restrict__ V, const float *__restrict__ O,
-                                                       const float *__restrict__ dO, int n,
-                                                       const float *__restrict__ stats, float *__restrict__ dQ,
-                                                       float *__restrict__ dK, float *__restrict__ dV,
-                                                       float *__restrict__ amax_dqkv) {     // [3]: bounds of |dQ|, |dK|, |dV|
-    extern __shared__ float sm[];              // Q, K, V, dO: [n][16] each; row max, 1 / row sum, dO.O: [n] each
-    float *Qs = sm, *Ks = Qs + n * HDIM, *Vs = Ks + n * HDIM, *Gs = Vs + n * HDIM;
-    float *Mx = Gs + n * HDIM, *Inv = Mx + n, *Dt = Inv + n;
-    const int r = blockIdx.x, hd = blockIdx.y, i = threadIdx.x;
+// dS is scaled for the binary16 operands by a bound of its magnitude, |dS[i][j]| <= (|dO_i|_1 max|V| + |dO_i . O_i|) / 4.
+//
+// attn_bwd_q_kernel: a wave owns 32 queries and walks over the key tiles (score tiles transposed, as in the forward).
+__global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+                                                         const float *__restrict__ V, const float *__restrict__ O,
+                                                         const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
+                                                         const float *__restrict__ amax_do, const float *__restrict__ stats,
+                                                         float *__restrict__ dQ, float *__restrict__ amax_dq) {
+    extern __shared__ __align__(16) _Float16 att_lds[];
+    const int NT = blockDim.x >> 6, n_pad = 32 * NT, TS = ATT_TS(NT);
+    _Float16 *Kh = att_lds, *Kl = Kh + n_pad * 16, *Vh = Kl + n_pad * 16, *Vl = Vh + n_pad * 16, *KTh = Vl + n_pad * 16, *KTl = KTh + 16 * TS;
+    const int r = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x & 63, it = threadIdx.x >> 6, q = lane & 31, h = lane >> 5;
     const long tok0 = (long)r * n;
-    stage_head(Q, tok0, n, hd, Qs);
-    stage_head(K, tok0, n, hd, Ks);
-    stage_head(V, tok0, n, hd, Vs);
-    stage_head(dO, tok0, n, hd, Gs);
-    const bool live = i < n;
-    if (live) {
-        const float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
-        Mx[i] = st[0];
-        Inv[i] = 1.0f / st[1];
-        float d = 0.0f;
+    const float bound_v = amax_read(amax_qkv + 2 * AMAX_STRIDE);
+    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
+                sv = pow2_scale_for(bound_v), sg = pow2_scale_for(amax_read(amax_do));
+    stage_head_split(K, tok0, n, n_pad, hd, sk, Kh, Kl, KTh, KTl, TS);
+    stage_head_split(V, tok0, n, n_pad, hd, sv, Vh, Vl, nullptr, nullptr, TS);
+    const int i = 32 * it + q;
+    float qv[8], gv[8], ov[8];
+    load_own_rows(Q, tok0, n, i, hd, h, qv);
+    load_own_rows(dO, tok0, n, i, hd, h, gv);
+    load_own_rows(O, tok0, n, i, hd, h, ov);
+    float dt = 0.0f, l1 = 0.0f;
 #pragma unroll
-        for (int c = 0; c < HDIM; ++c) {
-            const long g = (tok0 + i) * D_MODEL + hd * HDIM + c;
-            d = fmaf(dO[g], O[g], d);
-        }
-        Dt[i] = d;
+    for (int e = 0; e < 8; ++e) { dt = fmaf(gv[e], ov[e], dt); l1 += fabsf(gv[e]); }
+    dt += __shfl_xor(dt, 32, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    const float c = pow2_scale_for((l1 * bound_v + fabsf(dt)) * 0.25f);       // per query: a column of the dS^T operand
+    f16x8 qh, ql, gh, gl;
+    split8(qv, sq, qh, ql);
+    split8(gv, sg, gh, gl);
+    float mx = 0.0f, inv = 1.0f;
+    if (i < n) {
+        const float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
+        mx = st[0];
+        inv = 1.0f / st[1];
     }
     __syncthreads();
-    float mq = 0.0f, mk = 0.0f, mv = 0.0f;
-    if (live) {   // thread = query i
-        float q[HDIM], go[HDIM], a[HDIM];
+    const float cs = 0.25f / (sq * sk), cg = 1.0f / (sv * sg);
+    f32x16 dq = zero16();
+    for (int jt = 0; jt < NT; ++jt) {
+        const int ko = rm_off(32 * jt + q, h);
+        f32x16 sc = mfma_split(*reinterpret_cast<const f16x8 *>(Kh + ko), *reinterpret_cast<const f16x8 *>(Kl + ko), qh, ql, zero16());
+        const f32x16 dp = mfma_split(*reinterpret_cast<const f16x8 *>(Vh + ko), *reinterpret_cast<const f16x8 *>(Vl + ko), gh, gl, zero16());
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) { q[d] = Qs[i * HDIM + d]; go[d] = Gs[i * HDIM + d]; a[d] = 0.0f; }
-        const float mx = Mx[i], inv = Inv[i], dt = Dt[i];
-        for (int j = 0; j < n; ++j) {
-            const float p = expf(dot16(q, Ks + j * HDIM) / 4.0f - mx) * inv;
-            const float ds = p * (dot16(go, Vs + j * HDIM) - dt) / 4.0f;
-            axpy16(a, ds, Ks + j * HDIM);
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float p = j < n ? exp_neg(sc[e] * cs - mx) * inv : 0.0f;
+            sc[e] = p * (dp[e] * cg - dt) * 0.25f;                              // dS[i][j]
         }
 #pragma unroll
-        for (int d = 0; d < HDIM; ++d) {
-            dQ[(tok0 + i) * D_MODEL + hd * HDIM + d] = a[d];
-            mq = fmaxf(mq, fabsf(a[d]));
-        }
-    }
-    if (live) {   // thread = key j (= i)
-        float k[HDIM], v[HDIM], ak[HDIM], av[HDIM];
-#pragma unroll
-        for (int d = 0; d < HDIM; ++d) { k[d] = Ks[i * HDIM + d]; v[d] = Vs[i * HDIM + d]; ak[d] = 0.0f; av[d] = 0.0f; }
-        for (int t = 0; t < n; ++t) {
-            const float p = expf(dot16(k, Qs + t * HDIM) / 4.0f - Mx[t]) * Inv[t];
-            const float ds = p * (dot16(v, Gs + t * HDIM) - Dt[t]) / 4.0f;
-            axpy16(av, p, Gs + t * HDIM);
-            axpy16(ak, ds, Qs + t * HDIM);
-        }
-#pragma unroll
-        for (int d = 0; d < HDIM; ++d) {
-            dK[(tok0 + i) * D_MODEL + hd * HDIM + d] = ak[d];
-            dV[(tok0 + i) * D_MODEL + hd * HDIM + d] = av[d];
-            mk = fmaxf(mk, fabsf(ak[d]));
-            mv = fmaxf(mv, fabsf(av[d]));
+        for (int s = 0; s < 2; ++s) {
+            f16x8 dh, dl;
+            acc_operand(sc, s, c, dh, dl);
+            dq = mfma_split(t_operand(KTh, TS, q & 15, jt, s, h), t_operand(KTl, TS, q & 15, jt, s, h), dh, dl, dq);
         }
     }
-    mq = wave_max_f32(mq);
+    float m = 0.0f;
+    if (i < n) m = store_head_rows(dQ + (tok0 + i) * D_MODEL + hd * HDIM, dq, 1.0f / (sk * c), h);
+    m = wave_max_f32(m);
+    if (lane == 0) atomic_max_abs(amax_dq, m);
+}
+
+// attn_bwd_kv_kernel: a wave owns 32 keys and walks over the query tiles (score tiles with queries along the rows:
+// the per-query statistics come from LDS, four consecutive queries per accumulator register group).
+__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+                                                          const float *__restrict__ V, const float *__restrict__ O,
+                                                          const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
+                                                          const float *__restrict__ amax_do, const float *__restrict__ stats,
+                                                          float *__restrict__ dK, float *__restrict__ dV,
+                                                          float *__restrict__ amax_dkv) {        // bounds of |dK|, |dV|
+    extern __shared__ __align__(16) _Float16 att_lds[];
+    const int NT = blockDim.x >> 6, n_pad = 32 * NT, TS = ATT_TS(NT);
+    _Float16 *Qh = att_lds, *Ql = Qh + n_pad * 16, *Gh = Ql + n_pad * 16, *Gl = Gh + n_pad * 16;
+    _Float16 *QTh = Gl + n_pad * 16, *QTl = QTh + 16 * TS, *GTh = QTl + 16 * TS, *GTl = GTh + 16 * TS;
+    float *Mx = reinterpret_cast<float *>(GTl + 16 * TS), *Inv = Mx + n_pad, *Dt = Inv + n_pad;
+    unsigned *bound_bits = reinterpret_cast<unsigned *>(Dt + n_pad);
+    const int r = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x & 63, jt = threadIdx.x >> 6, q = lane & 31, h = lane >> 5;
+    const long tok0 = (long)r * n;
+    const float bound_v = amax_read(amax_qkv + 2 * AMAX_STRIDE);
+    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
+                sv = pow2_scale_for(bound_v), sg = pow2_scale_for(amax_read(amax_do));
+    if (threadIdx.x == 0) *bound_bits = 0u;
+    stage_head_split(Q, tok0, n, n_pad, hd, sq, Qh, Ql, QTh, QTl, TS);
+    stage_head_split(dO, tok0, n, n_pad, hd, sg, Gh, Gl, GTh, GTl, TS);
+    __syncthreads();
+    {   // per query: row maximum, 1 / row sum, dO.O, and the bound of its dS entries
+        const int t = threadIdx.x;
+        float mxv = 0.0f, iv = 0.0f, d = 0.0f, l1 = 0.0f;
+        if (t < n) {
+            const float *st = stats + (((long)r * HEADS + hd) * n + t) * 2;
+            mxv = st[0];
+            iv = 1.0f / st[1];
+            const float *pg = dO + (tok0 + t) * D_MODEL + hd * HDIM, *po = O + (tok0 + t) * D_MODEL + hd * HDIM;
+#pragma unroll
+            for (int e = 0; e < HDIM; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(pg + e), o4 = *reinterpret_cast<const float4 *>(po + e);
+                d = fmaf(g4.x, o4.x, d); d = fmaf(g4.y, o4.y, d); d = fmaf(g4.z, o4.z, d); d = fmaf(g4.w, o4.w, d);
+                l1 += fabsf(g4.x) + fabsf(g4.y) + fabsf(g4.z) + fabsf(g4.w);
+            }
+        }
+        if (t < n_pad) { Mx[t] = mxv; Inv[t] = iv; Dt[t] = d; }           // Inv = 0 beyond n: those rows' P vanish
+        float b = wave_max_f32((l1 * bound_v + fabsf(d)) * 0.25f);
+        if (lane == 0) atomicMax(bound_bits, __float_as_uint(b));
+    }
+    const int j = 32 * jt + q;
+    float kv[8], vv[8];
+    load_own_rows(K, tok0, n, j, hd, h, kv);
+    load_own_rows(V, tok0, n, j, hd, h, vv);
+    f16x8 kh, kl, vh, vl;
+    split8(kv, sk, kh, kl);
+    split8(vv, sv, vh, vl);
+    __syncthreads();
+    const float c = pow2_scale_for(__uint_as_float(*bound_bits));
+    const float cs = 0.25f / (sq * sk), cg = 1.0f / (sv * sg);
+    f32x16 dk = zero16(), dv = zero16();
+    for (int it = 0; it < NT; ++it) {
+        const int qo = rm_off(32 * it + q, h);
+        f32x16 sc = mfma_split(*reinterpret_cast<const f16x8 *>(Qh + qo), *reinterpret_cast<const f16x8 *>(Ql + qo), kh, kl, zero16());
+        f32x16 dp = mfma_split(*reinterpret_cast<const f16x8 *>(Gh + qo), *reinterpret_cast<const f16x8 *>(Gl + qo), vh, vl, zero16());
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int i0 = 32 * it + 8 * g4 + 4 * h;
+            const float4 m4 = *reinterpret_cast<const float4 *>(Mx + i0), v4 = *reinterpret_cast<const float4 *>(Inv + i0),
+                         d4 = *reinterpret_cast<const float4 *>(Dt + i0);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {v4.x, v4.y, v4.z, v4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = exp_neg(sc[4 * g4 + e] * cs - mm[e]) * ii[e];
+                sc[4 * g4 + e] = p;                                               // P[i][j]
+                dp[4 * g4 + e] = p * (dp[4 * g4 + e] * cg - dd[e]) * 0.25f;       // dS[i][j]
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ph, pl, dh, dl;
+            acc_operand(sc, s, 1024.0f, ph, pl);
+            acc_operand(dp, s, c, dh, dl);
+            dv = mfma_split(t_operand(GTh, TS, q & 15, it, s, h), t_operand(GTl, TS, q & 15, it, s, h), ph, pl, dv);
+            dk = mfma_split(t_operand(QTh, TS, q & 15, it, s, h), t_operand(QTl, TS, q & 15, it, s, h), dh, dl, dk);
+        }
+    }
+    float mk = 0.0f, mv = 0.0f;
+    if (j < n) {
+        mk = store_head_rows(dK + (tok0 + j) * D_MODEL + hd * HDIM, dk, 1.0f / (sq * c), h);
+        mv = store_head_rows(dV + (tok0 + j) * D_MODEL + hd * HDIM, dv, 1.0f / (1024.0f * sg), h);
+    }
     mk = wave_max_f32(mk);
     mv = wave_max_f32(mv);
-    if ((threadIdx.x & 63) == 0) {
-        atomic_max_abs(amax_dqkv, mq);
-        atomic_max_abs(amax_dqkv + AMAX_STRIDE, mk);
-        atomic_max_abs(amax_dqkv + 2 * AMAX_STRIDE, mv);
+    if (lane == 0) {
+        atomic_max_abs(amax_dkv, mk);
+        atomic_max_abs(amax_dkv + AMAX_STRIDE, mv);
     }
+}
+static size_t attn_lds_bytes(int NT, int rm_images, int t_images, int stat_floats) {
+    return (size_t)2 * 2 * (rm_images * 32 * NT * 16 + t_images * 16 * ATT_TS(NT)) + (size_t)stat_floats * 4;
 }
 
 // ------------------------------------------------------------------------------ anchors
@@ -841,6 +1054,7 @@ enum {
     AX_DB = 26,      // +l: gradient with respect to AO[l]
     AX_DQKV = 30,    // +3l: dQ, dK, dV of block l
     AX_DH = 42,      // +l
+    AX_QKV = 46,     // +3l: Q, K, V of block l
 };
 static size_t part_floats(int R, int n) {
     const size_t M = (size_t)R * n;
@@ -926,9 +1140,10 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     const int anchor0 = io->k_last, anchor1 = n - 1;
     const bool cvrp = io->problem == DGL_PROBLEM_CVRP;
     const int n_anchor = cvrp ? 2 : 1;
-    const size_t attn_lds = (size_t)2 * n * HDIM * sizeof(float), attn_bwd_lds = 2 * attn_lds + (size_t)3 * n * sizeof(float);
-    if (attn_bwd_lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    const int NT = (n + 31) / 32;                      // attention: 32-token tiles, one wave each
+    const size_t attn_fwd_lds = attn_lds_bytes(NT, 1, 1, 0), attn_q_lds = attn_lds_bytes(NT, 2, 1, 0),
+                 attn_kv_lds = attn_lds_bytes(NT, 2, 2, 3 * 32 * NT + 4);
+    (void)hipFuncSetAttribute((const void *)attn_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
 
     // ---- forward
     (void)hipMemsetAsync(ax, 0, AMAX_FLOATS * sizeof(float), s);
@@ -947,11 +1162,12 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0], bound(AX_X + 1));
         }
         GemmLaunch()
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wq, nullptr, Qb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wk, nullptr, Kb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wv, nullptr, Vb[l], nullptr, D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wq, nullptr, Qb[l], bound(AX_QKV + 3 * l), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wk, nullptr, Kb[l], bound(AX_QKV + 3 * l + 1), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
+            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wv, nullptr, Vb[l], bound(AX_QKV + 3 * l + 2), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
             .run(s);
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(256), attn_lds, s, Qb[l], Kb[l], Vb[l], n, P[l], AO[l], bound(AX_AO + l));
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(64 * NT), attn_fwd_lds, s, Qb[l], Kb[l], Vb[l], n, bound(AX_QKV + 3 * l), P[l],
+                           AO[l], bound(AX_AO + l));
         GemmLaunch()
             .add(linear_fwd(AO[l], bound(AX_AO + l), D_MODEL, k.wc, k.bc, O1[l], bound(AX_O1 + l), D_MODEL, M, D_MODEL, D_MODEL, false, Xin,
                             D_MODEL))
@@ -1008,8 +1224,10 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
                               D_MODEL, D_MODEL))
             .add(linear_bwd_x(dA, ax_mid, D_MODEL, k.wc, dB, bound(AX_DB + l), D_MODEL, M, D_MODEL, D_MODEL, 0))       // dB = dAO
             .run(s);
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS), dim3(256), attn_bwd_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n, P[l], dQ,
-                           dK, dV, bound(AX_DQKV + 3 * l));
+        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(R, HEADS), dim3(64 * NT), attn_q_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
+                           bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dQ, bound(AX_DQKV + 3 * l));
+        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(R, HEADS), dim3(64 * NT), attn_kv_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
+                           bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dK, dV, bound(AX_DQKV + 3 * l + 1));
         // dXin = dA + dQ Wq + dK Wk + dV Wv: the three products accumulate in one tile, added to dA in place
         GemmArgs dx = linear_bwd_x(dQ, ax_q, D_MODEL, k.wq, dA, bound(AX_DX + l), D_MODEL, M, D_MODEL, D_MODEL, 0);
         dx.A[1] = dK; dx.B[1] = k.wk; dx.amax_a[1] = ax_q + AMAX_STRIDE;

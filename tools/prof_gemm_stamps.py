@@ -26,10 +26,10 @@ assert lib.dgl_debug_gemm_stamps_clear() == 0
 tr.zero_grad(); tr.forward_backward(eng, teacher); tr.optimizer_step()
 torch.cuda.synchronize()
 WGS = 4096
-buf = np.zeros(64 * WGS * 8, dtype=np.uint64)
+buf = np.zeros(64 * WGS * 16, dtype=np.uint64)
 lib.dgl_debug_gemm_stamps.restype = ctypes.c_int
 assert lib.dgl_debug_gemm_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-buf = buf.reshape(64, WGS, 8).astype(np.int64)
+buf = buf.reshape(64, WGS, 16).astype(np.int64)
 names = ["start", "loads+stage0", "barrier", "rest of K", "epilogue", "amax"]
 for L in range(64):
     b = buf[L]
@@ -42,3 +42,8 @@ for L in range(64):
     print(f"launch slot {L}: {live.sum()} live workgroups, span {s[:, 6].max() - t0} ticks; start spread {np.percentile(s[:, 0] - t0, [50, 90, 100]).astype(int)}; "
           f"per-workgroup total median {np.median(s[:, 6] - s[:, 0]):.0f}")
     print("    " + "  ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names)))
+    s2 = s[s[:, 14] > 0]
+    if len(s2):
+        d2 = np.diff(s2[:, 8:15], axis=1)
+        n2 = ["wait loads", "split+LDS writes", "barrier", "issue next loads", "MFMA", "barrier"]
+        print(f"    second stage ({len(s2)} workgroups): " + "  ".join(f"{n} {np.median(d2[:, i]):.0f}" for i, n in enumerate(n2)))
