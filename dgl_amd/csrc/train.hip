@@ -18,6 +18,7 @@
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define HEADS 8
 #define HDIM 16
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // ------------------------------------------------------------------------------- GEMM
 // C[i][j] (op)= sum over segments s, kk of A_s(i,kk) B_s(kk,j),  A(i,kk) = A[i*sai + kk*sak],  B(kk,j) = B[kk*sbk + j*sbn],
@@ -429,6 +430,220 @@ static GemmArgs linear_bwd_w(const float *dY, const float *amax_dy, long row_str
     return g;
 }
 
+// ------------------------------------------------------------ activation x weight GEMM
+// Y[M][N] (op)= sum over segments s of A_s[M][K] B_s, B_s a weight matrix (or its transpose) of the model, K and N
+// multiples of 128: every product of the forward pass and every dX product of the backward pass.
+//
+// The weights are split into binary16 halves once per call, in the order in which the matrix cores read them
+// (pack_weights_kernel): the B operand of 32 output columns and one k-step is 1 KB of hi halves and 1 KB of lo
+// halves, lane after lane, so a wave reads its operands straight from memory (L2-resident) into registers, 16 KB of
+// consecutive addresses per eight k-steps, double-buffered - no LDS, no conversion, no barrier in the loop.  A
+// workgroup owns 32 rows of A, converts them ONCE into an LDS image and sweeps all N output columns with it (wave w
+// takes the 32-column tiles w, w + 4, ...); several products with the same A (Q, K, V) share one image, and the
+// segments of one product (dQ Wq + dK Wk + dV Wv) accumulate in the same tile.
+//   packed B: [N / 32][Kd / 16][hi, lo][64 lanes][8 halfs],  lane (q, h) slot e  <->  B(16 t + 8 h + e, 32 jt + q)
+#define AW_SEGS 3
+struct AwProduct {
+    const _Float16 *Bp[AW_SEGS];
+    float *C;
+    const float *bias, *add, *gate;
+    float *amax_c;
+    int ldc, ldadd, mode, relu;          // mode 0: C = acc (+ bias) (ReLU) (gate) (+ add);  mode 1: C += acc
+};
+struct AwArgs {
+    const float *A[AW_SEGS];
+    const float *amax_a[AW_SEGS];
+    int nseg, lda, M, N;                 // every product has N columns
+    AwProduct p[3];
+    int nprod;
+};
+
+// B(k, j) = W[j * ld + k] (transposed == 0: Y = X W^T) or W[k * ld + j] (transposed: dX = dY W), Kd x Jd
+struct PackItem {
+    const float *W;
+    _Float16 *dst;
+    int Kd, Jd, ld, transposed;
+};
+#define PACK_ITEMS_MAX 48
+struct PackBatch {
+    PackItem it[PACK_ITEMS_MAX];
+    int first[PACK_ITEMS_MAX + 1];       // first workgroup of each item
+    int count;
+};
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch batch) {
+    int b = 0;
+    while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
+    const PackItem &it = batch.it[b];
+    const int idx = (blockIdx.x - batch.first[b]) * 256 + threadIdx.x;       // (jt, t, lane)
+    const int ksteps = it.Kd / 16;
+    if (idx >= (it.Jd / 32) * ksteps * 64) return;
+    const int lane = idx & 63, t = (idx >> 6) % ksteps, jt = (idx >> 6) / ksteps, q = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * t + 8 * h + e, j = 32 * jt + q;
+        v[e] = it.transposed ? it.W[(long)k * it.ld + j] : it.W[(long)j * it.ld + k];
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned a, c;
+        split2(v[2 * e], v[2 * e + 1], a, c);
+        hi[e] = a; lo[e] = c;
+    }
+    u32x4 *dst = reinterpret_cast<u32x4 *>(it.dst) + ((long)(jt * ksteps + t) * 2) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
+    extern __shared__ __align__(16) _Float16 aw_lds[];       // [nseg][hi, lo][32][K + 8]
+    constexpr int LDA = K + 8, CH = K / 128, NL = (32 * K / 4) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32;
+    const int tpp = a.N / 128;                                // tiles per wave and product
+    const int G = a.nprod * tpp * a.nseg * CH;                // chunks of eight k-steps this wave walks through
+    // the wave's B operands of chunk g: 16 KB of consecutive addresses
+    auto chunk_ptr = [&](int g) {
+        const int c = g % CH, seg = (g / CH) % a.nseg, tile = g / (CH * a.nseg);
+        const int jt = w + 4 * (tile % tpp);
+        return reinterpret_cast<const u32x4 *>(a.p[tile / tpp].Bp[seg]) + ((long)(jt * (K / 16) + 8 * c) * 2) * 64 + lane;
+    };
+    u32x4 b0[16], b1[16];
+    auto load_chunk = [&](u32x4 (&b)[16], int g) {
+        const u32x4 *p = chunk_ptr(g);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b[e] = p[64 * e];
+    };
+    // ---- the A rows: loads, then the first B chunk, then the scale, split and the LDS image
+    float sa = 1.0f;
+    {
+        float4 v[AW_SEGS > 1 && K == 128 ? AW_SEGS * NL : NL];
+        const int nsegs = K == 128 ? a.nseg : 1;
+#pragma unroll
+        for (int seg = 0; seg < (K == 128 ? AW_SEGS : 1); ++seg) {
+            if (seg < nsegs) {
+#pragma unroll
+                for (int e = 0; e < NL; ++e) {
+                    const int idx = tid + 256 * e, row = idx / (K / 4), c4 = idx % (K / 4);
+                    v[seg * NL + e] = i0 + row < a.M ? *reinterpret_cast<const float4 *>(a.A[seg] + (long)(i0 + row) * a.lda + 4 * c4)
+                                                     : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        }
+        load_chunk(b0, 0);
+        float bound = 0.0f;
+        bool scaled = false;
+        for (int seg = 0; seg < nsegs; ++seg)
+            if (a.amax_a[seg]) { bound = fmaxf(bound, amax_read(a.amax_a[seg])); scaled = true; }
+        if (scaled) sa = pow2_scale_for(bound);
+#pragma unroll
+        for (int seg = 0; seg < (K == 128 ? AW_SEGS : 1); ++seg) {
+            if (seg < nsegs) {
+                _Float16 *H = aw_lds + seg * 2 * 32 * LDA, *L = H + 32 * LDA;
+#pragma unroll
+                for (int e = 0; e < NL; ++e) {
+                    const int idx = tid + 256 * e, row = idx / (K / 4), c4 = idx % (K / 4);
+                    const float4 x = v[seg * NL + e];
+                    unsigned h0, l0, h1, l1;
+                    split2(x.x * sa, x.y * sa, h0, l0);
+                    split2(x.z * sa, x.w * sa, h1, l1);
+                    *reinterpret_cast<u32x2 *>(H + row * LDA + 4 * c4) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2 *>(L + row * LDA + 4 * c4) = u32x2{l0, l1};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float unscale = 1.0f / sa;
+    const bool full_rows = i0 + 32 <= a.M;
+    f32x16 acc = zero16();
+    float other[16], gate[16], bias_j = 0.0f;
+    // one chunk: eight k-steps from registers `b`, the next chunk's loads issued first
+    auto chunk = [&](int g, u32x4 (&b)[16], u32x4 (&bn)[16]) {
+        if (g + 1 < G) load_chunk(bn, g + 1);
+        const int c = g % CH, seg = (g / CH) % a.nseg, tile = g / (CH * a.nseg);
+        const AwProduct &P = a.p[tile / tpp];
+        const int j = 32 * (w + 4 * (tile % tpp)) + q;
+        const bool last = c == CH - 1 && seg == a.nseg - 1;
+        if (c == 0 && seg == 0) acc = zero16();
+        if (last) {
+            // what the epilogue combines with the product, in flight during the last MFMAs (and all of it before the
+            // first store: C, add and gate may alias as far as the compiler can tell)
+            bias_j = (P.mode == 0 && P.bias) ? P.bias[j] : 0.0f;
+            const float *src = P.mode == 1 ? P.C : P.add;
+            const int lds_ = P.mode == 1 ? P.ldc : P.ldadd;
+            const bool has_other = P.mode == 1 || P.add != nullptr, has_gate = P.mode == 0 && P.gate != nullptr;
+            // (uniform branches: a guard per row and lane would turn every load into a branch of its own)
+            if (has_other && full_rows) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) other[r] = src[(long)(i0 + (r & 3) + 8 * (r >> 2) + 4 * h) * lds_ + j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    other[r] = (has_other && i < a.M) ? src[(long)i * lds_ + j] : 0.0f;
+                }
+            }
+            if (has_gate && full_rows) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gate[r] = P.gate[(long)(i0 + (r & 3) + 8 * (r >> 2) + 4 * h) * P.ldc + j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    gate[r] = (has_gate && i < a.M) ? P.gate[(long)i * P.ldc + j] : 1.0f;
+                }
+            }
+        }
+        const _Float16 *Ah = aw_lds + seg * 2 * 32 * LDA + q * LDA + 128 * c + 8 * h, *Al = Ah + 32 * LDA;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ah + 16 * t), al = *reinterpret_cast<const f16x8 *>(Al + 16 * t);
+            const f16x8 bh = as_f16x8(b[2 * t]), bl = as_f16x8(b[2 * t + 1]);
+            acc = MFMA16(al, bh, acc);
+            acc = MFMA16(ah, bl, acc);
+            acc = MFMA16(ah, bh, acc);
+        }
+        if (last) {
+            float cmax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!full_rows && i >= a.M) continue;
+                float v = acc[r] * unscale;
+                if (P.mode == 0) {
+                    v += bias_j;
+                    if (P.relu) v = fmaxf(v, 0.0f);
+                    if (!(gate[r] > 0.0f)) v = 0.0f;
+                }
+                v = other[r] + v;
+                P.C[(long)i * P.ldc + j] = v;
+                cmax = fmaxf(cmax, fabsf(v));
+            }
+            if (P.amax_c) {
+                cmax = wave_max_f32(cmax);
+                if (lane == 0) atomic_max_abs(P.amax_c, cmax);
+            }
+        }
+    };
+    for (int g = 0; g < G; g += 2) {
+        chunk(g, b0, b1);
+        if (g + 1 < G) chunk(g + 1, b1, b0);
+    }
+}
+static size_t aw_lds_bytes(int K, int nseg) { return (size_t)nseg * 2 * 32 * (K + 8) * 2; }
+static void launch_aw(hipStream_t s, const AwArgs &a, int K) {
+    const int blocks = (a.M + 31) / 32;
+    if (K == 128) {
+        hipLaunchKernelGGL(gemm_aw_kernel<128>, dim3(blocks), dim3(256), aw_lds_bytes(128, a.nseg), s, a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)gemm_aw_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
+        hipLaunchKernelGGL(gemm_aw_kernel<512>, dim3(blocks), dim3(256), aw_lds_bytes(512, 1), s, a);
+    }
+}
+
 // dst[e] += part[0][e] + part[1][e] + ... (in that order), e < count, rows `stride` floats apart: the ordered sum of the
 // partial products / partial column sums.  Several sums share one launch (block ranges as in gemm_kernel).
 #define REDUCE_BATCH_MAX 16
@@ -529,7 +744,6 @@ __device__ __forceinline__ float exp_neg(float x) {
     const float e = __builtin_amdgcn_exp2f(t);
     return fmaf(e, lo * 0.693147182f, e);
 }
-__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // stages head hd of src rows tok0 .. tok0 + n - 1 (times scale) into the images that are given (else nullptr)
 __device__ __forceinline__ void stage_head_split(const float *__restrict__ src, long tok0, int n, int n_pad, int hd, float scale,
@@ -1041,7 +1255,7 @@ extern "C" int dgl_adam_step(float *params, const float *grads, float *exp_avg, 
 //   magnitude bounds [64][16 parts, 128 bytes apart] | T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | E [M][128] (encoder
 //   output before the anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row
 //   statistics [R][8][n][2] | backward scratch: dA dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
-//   block's weight and bias gradients
+//   block's weight and bias gradients | packed weights
 #define AMAX_SLOTS 64
 #define AMAX_FLOATS (AMAX_SLOTS * AMAX_STRIDE)
 enum {
@@ -1056,6 +1270,9 @@ enum {
     AX_DH = 42,      // +l
     AX_QKV = 46,     // +3l: Q, K, V of block l
 };
+// packed weights of the four blocks, for the forward products and (transposed) for the dX products: hi + lo halves = 4 bytes a weight
+#define BLOCK_WEIGHTS (4 * D_MODEL * D_MODEL + 2 * D_MODEL * FF_DIM)
+#define PACKED_FLOATS (2 * 4 * BLOCK_WEIGHTS)
 static size_t part_floats(int R, int n) {
     const size_t M = (size_t)R * n;
     const size_t zm = (M + DW_CHUNK - 1) / DW_CHUNK, zr = ((size_t)R + DW_CHUNK - 1) / DW_CHUNK;
@@ -1068,7 +1285,8 @@ static size_t part_floats(int R, int n) {
 static size_t ws_floats(int R, int n) {
     const size_t M = (size_t)R * n;
     const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * 2;
-    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM + part_floats(R, n);
+    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM + part_floats(R, n) +
+           PACKED_FLOATS;
 }
 extern "C" int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n) { return (int64_t)ws_floats(R, n); }
 
@@ -1137,6 +1355,45 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     float *dV = p; p += MD;
     float *dH = p; p += MF;
     PartialSums ps(p, part_floats(R, n));
+    p += part_floats(R, n);
+    const bool train = grad != nullptr;
+    // packed weights: [block][wq wk wv wc w1 w2] for Y = X W^T, then the same for dX = dY W
+    _Float16 *packed = reinterpret_cast<_Float16 *>(p);
+    const _Float16 *pk[2][4][6];
+    {
+        PackBatch pb;
+        pb.count = 0;
+        int blocks = 0;
+        _Float16 *dst = packed;
+        for (int tr = 0; tr < (train ? 2 : 1); ++tr)
+            for (int l = 0; l < 4; ++l) {
+                const dgl_block_weights_t &k = w->block[l];
+                const float *W[6] = {k.wq, k.wk, k.wv, k.wc, k.w1, k.w2};
+                const int rows[6] = {D_MODEL, D_MODEL, D_MODEL, D_MODEL, FF_DIM, D_MODEL}, cols[6] = {D_MODEL, D_MODEL, D_MODEL, D_MODEL, D_MODEL, FF_DIM};
+                for (int m = 0; m < 6; ++m) {
+                    // W [rows][cols]: Y = X W^T reduces over cols, dX = dY W over rows
+                    PackItem it{W[m], dst, tr ? rows[m] : cols[m], tr ? cols[m] : rows[m], cols[m], tr};
+                    pb.it[pb.count] = it;
+                    pb.first[pb.count++] = blocks;
+                    blocks += (it.Jd / 32) * (it.Kd / 16) * 64 / 256;
+                    pk[tr][l][m] = dst;
+                    dst += 2 * (size_t)rows[m] * cols[m];
+                }
+            }
+        pb.first[pb.count] = blocks;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pb);
+    }
+    // one product of the activation x weight kernel
+    auto aw_product = [](const _Float16 *Bp, float *C, float *amax_c, int ldc) {
+        AwProduct P{};
+        P.Bp[0] = Bp; P.C = C; P.amax_c = amax_c; P.ldc = ldc;
+        return P;
+    };
+    auto aw_args = [M](const float *A, const float *amax_a, int lda, int N) {
+        AwArgs a{};
+        a.A[0] = A; a.amax_a[0] = amax_a; a.nseg = 1; a.lda = lda; a.M = M; a.N = N; a.nprod = 1;
+        return a;
+    };
     const int anchor0 = io->k_last, anchor1 = n - 1;
     const bool cvrp = io->problem == DGL_PROBLEM_CVRP;
     const int n_anchor = cvrp ? 2 : 1;
@@ -1161,26 +1418,35 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, X[1], n, anchor0, anchor1,
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0], bound(AX_X + 1));
         }
-        GemmLaunch()
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wq, nullptr, Qb[l], bound(AX_QKV + 3 * l), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wk, nullptr, Kb[l], bound(AX_QKV + 3 * l + 1), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .add(linear_fwd(Xin, ax_in, D_MODEL, k.wv, nullptr, Vb[l], bound(AX_QKV + 3 * l + 2), D_MODEL, M, D_MODEL, D_MODEL, false, nullptr, 0))
-            .run(s);
+        {   // Q, K, V: three products with the same A
+            AwArgs a = aw_args(Xin, ax_in, D_MODEL, D_MODEL);
+            a.p[0] = aw_product(pk[0][l][0], Qb[l], bound(AX_QKV + 3 * l), D_MODEL);
+            a.p[1] = aw_product(pk[0][l][1], Kb[l], bound(AX_QKV + 3 * l + 1), D_MODEL);
+            a.p[2] = aw_product(pk[0][l][2], Vb[l], bound(AX_QKV + 3 * l + 2), D_MODEL);
+            a.nprod = 3;
+            launch_aw(s, a, D_MODEL);
+        }
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(64 * NT), attn_fwd_lds, s, Qb[l], Kb[l], Vb[l], n, bound(AX_QKV + 3 * l), P[l],
                            AO[l], bound(AX_AO + l));
-        GemmLaunch()
-            .add(linear_fwd(AO[l], bound(AX_AO + l), D_MODEL, k.wc, k.bc, O1[l], bound(AX_O1 + l), D_MODEL, M, D_MODEL, D_MODEL, false, Xin,
-                            D_MODEL))
-            .run(s);
-        GemmLaunch()
-            .add(linear_fwd(O1[l], bound(AX_O1 + l), D_MODEL, k.w1, k.b1, H[l], bound(AX_H + l), FF_DIM, M, FF_DIM, D_MODEL, true, nullptr, 0))
-            .run(s);
-        GemmLaunch()
-            .add(linear_fwd(H[l], bound(AX_H + l), FF_DIM, k.w2, k.b2, X[l + 1], bound(AX_X + l + 1), D_MODEL, M, D_MODEL, FF_DIM, false, O1[l],
-                            D_MODEL))
-            .run(s);
+        {   // O1 = Xin + Wc AO + bc
+            AwArgs a = aw_args(AO[l], bound(AX_AO + l), D_MODEL, D_MODEL);
+            a.p[0] = aw_product(pk[0][l][3], O1[l], bound(AX_O1 + l), D_MODEL);
+            a.p[0].bias = k.bc; a.p[0].add = Xin; a.p[0].ldadd = D_MODEL;
+            launch_aw(s, a, D_MODEL);
+        }
+        {   // H = relu(W1 O1 + b1)
+            AwArgs a = aw_args(O1[l], bound(AX_O1 + l), D_MODEL, FF_DIM);
+            a.p[0] = aw_product(pk[0][l][4], H[l], bound(AX_H + l), FF_DIM);
+            a.p[0].bias = k.b1; a.p[0].relu = 1;
+            launch_aw(s, a, D_MODEL);
+        }
+        {   // X[l+1] = O1 + W2 H + b2
+            AwArgs a = aw_args(H[l], bound(AX_H + l), FF_DIM, D_MODEL);
+            a.p[0] = aw_product(pk[0][l][5], X[l + 1], bound(AX_X + l + 1), D_MODEL);
+            a.p[0].bias = k.b2; a.p[0].add = O1[l]; a.p[0].ldadd = D_MODEL;
+            launch_aw(s, a, FF_DIM);
+        }
     }
-    const bool train = grad != nullptr;
     float *dwf_part = nullptr, *dbf_part = nullptr;
     if (train) {
         dwf_part = ps.take((float *)grad->final_w, R, D_MODEL);
@@ -1199,50 +1465,58 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         const float *Xin = X[l];
         const float *ax_out = bound(AX_DX + l + 1), *ax_h = bound(AX_DH + l), *ax_q = bound(AX_DQKV + 3 * l);
         float *ax_mid = bound(AX_DMID + l);
-        // Products that share no output run in one launch each; the weight-gradient product also sums its dY operand
-        // over the tokens (the bias gradient).
+        // The dX products run on the packed transposed weights; the weight-gradient products (which also sum their dY
+        // operand over the tokens: the bias gradient) are batched into launches between them.
         // X[l+1] = O1 + W2 H + b2;  H = relu(..): dH = (dA W2) where H > 0
-        GemmArgs dh = linear_bwd_x(dA, ax_out, D_MODEL, k.w2, dH, bound(AX_DH + l), FF_DIM, M, D_MODEL, FF_DIM, 0);
-        dh.gate = H[l];
-        float *b2_part = ps.take((float *)g.b2, zm, D_MODEL);
+        {
+            AwArgs a = aw_args(dA, ax_out, D_MODEL, FF_DIM);
+            a.p[0] = aw_product(pk[1][l][5], dH, bound(AX_DH + l), FF_DIM);
+            a.p[0].gate = H[l];
+            launch_aw(s, a, D_MODEL);
+        }
+        float *b2_part = ps.take((float *)g.b2, zm, D_MODEL), *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
         GemmLaunch()
             .add(linear_bwd_w(dA, ax_out, D_MODEL, H[l], bound(AX_H + l), FF_DIM, ps.take((float *)g.w2, zm, D_MODEL * FF_DIM), b2_part, M,
                               D_MODEL, FF_DIM))
-            .add(dh)
-            .run(s);
-        // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1   (accumulated into dA)
-        float *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
-        GemmLaunch()
             .add(linear_bwd_w(dH, ax_h, FF_DIM, O1[l], bound(AX_O1 + l), D_MODEL, ps.take((float *)g.w1, zm, FF_DIM * D_MODEL), b1_part, M,
                               FF_DIM, D_MODEL))
-            .add(linear_bwd_x(dH, ax_h, FF_DIM, k.w1, dA, ax_mid, D_MODEL, M, FF_DIM, D_MODEL, 1))
             .run(s);
-        // O1 = Xin + Wc AO + bc
-        float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
-        GemmLaunch()
-            .add(linear_bwd_w(dA, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
-                              D_MODEL, D_MODEL))
-            .add(linear_bwd_x(dA, ax_mid, D_MODEL, k.wc, dB, bound(AX_DB + l), D_MODEL, M, D_MODEL, D_MODEL, 0))       // dB = dAO
-            .run(s);
+        {   // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1   (accumulated into dA)
+            AwArgs a = aw_args(dH, ax_h, FF_DIM, D_MODEL);
+            a.p[0] = aw_product(pk[1][l][4], dA, ax_mid, D_MODEL);
+            a.p[0].mode = 1;
+            launch_aw(s, a, FF_DIM);
+        }
+        {   // O1 = Xin + Wc AO + bc:  dB = dAO = dA Wc
+            AwArgs a = aw_args(dA, ax_mid, D_MODEL, D_MODEL);
+            a.p[0] = aw_product(pk[1][l][3], dB, bound(AX_DB + l), D_MODEL);
+            launch_aw(s, a, D_MODEL);
+        }
         hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(R, HEADS), dim3(64 * NT), attn_q_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
                            bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dQ, bound(AX_DQKV + 3 * l));
         hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(R, HEADS), dim3(64 * NT), attn_kv_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
                            bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dK, dV, bound(AX_DQKV + 3 * l + 1));
-        // dXin = dA + dQ Wq + dK Wk + dV Wv: the three products accumulate in one tile, added to dA in place
-        GemmArgs dx = linear_bwd_x(dQ, ax_q, D_MODEL, k.wq, dA, bound(AX_DX + l), D_MODEL, M, D_MODEL, D_MODEL, 0);
-        dx.A[1] = dK; dx.B[1] = k.wk; dx.amax_a[1] = ax_q + AMAX_STRIDE;
-        dx.A[2] = dV; dx.B[2] = k.wv; dx.amax_a[2] = ax_q + 2 * AMAX_STRIDE;
-        dx.nseg = 3;
-        dx.add = dA; dx.ldadd = D_MODEL;
+        float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
         GemmLaunch()
+            .add(linear_bwd_w(dA, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
+                              D_MODEL, D_MODEL))
             .add(linear_bwd_w(dQ, ax_q, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wq, zm, D_MODEL * D_MODEL), nullptr, M,
                               D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL), nullptr, M,
-                              D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL), nullptr, M,
-                              D_MODEL, D_MODEL))
-            .add(dx)
+            .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL),
+                              nullptr, M, D_MODEL, D_MODEL))
+            .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL),
+                              nullptr, M, D_MODEL, D_MODEL))
             .run(s);
+        {   // dXin = dA + dQ Wq + dK Wk + dV Wv: the three products accumulate in one tile, added to dA in place
+            AwArgs a = aw_args(dQ, ax_q, D_MODEL, D_MODEL);
+            a.A[1] = dK; a.amax_a[1] = ax_q + AMAX_STRIDE;
+            a.A[2] = dV; a.amax_a[2] = ax_q + 2 * AMAX_STRIDE;
+            a.nseg = 3;
+            a.p[0] = aw_product(pk[1][l][0], dA, bound(AX_DX + l), D_MODEL);
+            a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
+            a.p[0].add = dA; a.p[0].ldadd = D_MODEL;
+            launch_aw(s, a, D_MODEL);
+        }
         if (l == 1) {
             // dW_a[c][k] += sum_r dA[anchor of row r][c] E[anchor of row r][k]: the rows' anchor tokens are n tokens apart
             GemmLaunch gl;

@@ -46,15 +46,17 @@ def _check_training(tr, g, what):
     likely = g["train/prob"] >= 1e-3
     worst = np.unravel_index(np.argmax(rel), rel.shape)
     print(f"   largest difference at step {worst[0] + 1}, row {worst[1]}: {probs[worst]:.4e} vs {g['train/prob'][worst]:.4e}")
-    # The weight gradients are sums of float atomics whose order differs from run to run; Adam turns that rounding
-    # noise into +-lr steps of ill-conditioned entries, and the trajectories drift apart as the steps accumulate
-    # (float32 against float64 autograd drifts the same way).  Early steps, before the drift: tight; all steps: the
-    # bound a few per cent of drift stays under with a wide margin (observed over repeated runs: 3e-5 and 2e-4 early,
-    # 3e-2 and 9e-2 overall).
+    # The device's gradients are reproducible bit for bit, but they are not the reference's bits (other summation
+    # orders, 22-bit products): Adam turns rounding differences into +-lr steps of ill-conditioned entries, and the
+    # trajectories drift apart as the steps accumulate (float32 against float64 autograd drifts the same way).
+    # Early steps, before the drift: tight; all steps: the bound a few per cent of drift stays under with a wide
+    # margin.
     early = min(12, probs.shape[0] // 3)
+    print(f"   early steps: likely {rel[:early][likely[:early]].max():.2e}, all {rel[:early].max():.2e}; "
+          f"all steps: likely {rel[likely].max():.2e}, all {rel.max():.2e}")
     assert np.median(rel) < 1e-4
-    assert rel[:early][likely[:early]].max() < 1e-3 and rel[:early].max() < 2e-3
-    assert rel[likely].max() < 0.1 and rel.max() < 0.3
+    assert rel[:early][likely[:early]].max() < 2e-4 and rel[:early].max() < 6e-4       # observed 5e-5 and 1.3e-4
+    assert rel[likely].max() < 0.1 and rel.max() < 0.15                                # observed 4e-2
     # Weights: Adam divides every entry's step by the entry's own gradient scale, so an entry whose gradient is
     # rounding noise (units that are almost dead, the last layer's biases whose gradients vanish identically,
     # saturated attention) still moves by +-lr per step, in a direction float32 autograd itself does not

@@ -100,6 +100,11 @@ def test_cvrp_train_step_matches_autograd(N, knn, kd, device):
     np.testing.assert_allclose(prob.cpu().numpy(), prob_ref.numpy(), rtol=2e-4)
     worst = _compare_grads(tr, orc, 2e-3)
     print(f"CVRP N={N} n={knn + kd + 2}: loss {loss_ref:.6f}, worst relative gradient error {worst:.2e}")
+    # sums over tokens are ordered sums of partial sums (no float atomics): a second evaluation gives the same bits
+    first = tr.grads.clone()
+    tr.zero_grad()
+    prob2 = tr.forward_backward(eng, teacher)
+    assert torch.equal(prob2, prob) and torch.equal(tr.grads, first), "gradients are not reproducible"
 
 
 def test_adam_matches_torch(device):

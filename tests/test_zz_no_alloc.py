@@ -48,8 +48,8 @@ def test_static_workspace_entry_point_matches_general(device):
     from oracle.dgl_oracle import random_weights
     w = random_weights("CVRP", 21)
     tr = PolicyTrainer(w, _lib.PROBLEM_CVRP, device)
-    # first call: 12 rows of 202 tokens (nearly the whole static workspace); second: 5 rows of 32 tokens
-    for B, N, knn, kd in ((12, 240, 100, 100), (5, 90, 15, 15)):
+    # first call: 10 rows of 202 tokens (nearly the whole static workspace); second: 5 rows of 32 tokens
+    for B, N, knn, kd in ((10, 240, 100, 100), (5, 90, 15, 15)):
         eng = _cvrp_case(B, N, knn, kd, device, seed=3 + B)
         assert eng.lib.dgl_policy_general_workspace_floats(B, knn + kd + 2) <= _lib.STATIC_WORKSPACE_FLOATS
         teacher = eng.idx_last[:, 1].clone()
@@ -59,9 +59,8 @@ def test_static_workspace_entry_point_matches_general(device):
         for a, b, what in zip(got[:4], ref[:4], ("logits", "probabilities", "greedy pick", "teacher probability")):
             assert torch.equal(a, b), f"B={B}: {what} differ"          # the forward pass is deterministic: same bits
         assert float(ref[3].min()) > 1e-20 and float(ref[4].abs().max()) > 0
-        # weight gradients are accumulated with float atomics (their order varies from launch to launch)
-        scale = float(ref[4].abs().max())
-        assert float((got[4] - ref[4]).abs().max()) <= 2e-5 * scale, f"B={B}: gradients differ"
+        # weight and bias gradients are ordered sums of partial sums: the same bits from every launch
+        assert torch.equal(got[4], ref[4]), f"B={B}: gradients differ"
 
 
 def test_static_workspace_rejects_oversize(device):
