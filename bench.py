@@ -59,8 +59,8 @@ def knn_bytes_per_row(nodes: int, k: int, cvrp: bool) -> float:
     return 24 * nodes + nodes / 8 + 8 * k
 
 
-KERNEL_SOURCES = ["policy16.hip", "policy.hip", "policy_layout.h", "tsp_state.hip", "cvrp_state.hip", "select.h",
-                  "state_common.h", "common.h"]
+KERNEL_SOURCES = ["policy16.hip", "policy16_body.h", "split_f16.h", "policy.hip", "policy_layout.h", "tsp_state.hip",
+                  "tsp_step_body.h", "cvrp_state.hip", "select.h", "state_common.h", "common.h"]
 
 
 def kernel_source_hash() -> str:
