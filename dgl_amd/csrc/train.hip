@@ -107,6 +107,7 @@ __device__ __forceinline__ float4 gemm_load4(const float *__restrict__ P, long s
 // Debug build (-DGEMM_STAMPS): wave 0 of every workgroup records the shader clock at the phase boundaries of its
 // tile; dgl_debug_gemm_stamps copies the records of the last 64 launches out.
 #ifdef GEMM_STAMPS
+static int gemm_launch_seq = 0;
 #define GEMM_STAMP_WGS 4096
 static __device__ unsigned long long gemm_stamp_buf[64 * GEMM_STAMP_WGS * 16];
 #define GSTAMP(i)                                                                                                           \
@@ -272,18 +273,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
             other[r] = (has_other && in) ? src[(long)i * lds_ + j] : 0.0f;
             gate[r] = (has_gate && in) ? g.gate[(long)i * g.ldc + j] : 1.0f;
         }
+        // (fields in registers before the first store: after a store through a float pointer the compiler re-reads
+        // every field it needs from the argument segment, one scalar round trip each)
+        const int ldc = g.ldc, rows = g.I;
+        const bool plain = g.mode == 0, relu = g.relu != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (!FULL && i >= g.I) continue;
+            if (!FULL && i >= rows) continue;
             float v = acc[r] * unscale;
-            if (g.mode == 0) {
+            if (plain) {
                 v += bias_j;
-                if (g.relu) v = fmaxf(v, 0.0f);
+                if (relu) v = fmaxf(v, 0.0f);
                 if (!(gate[r] > 0.0f)) v = 0.0f;
             }
             v = other[r] + v;
-            Cz[(long)i * g.ldc + j] = v;
+            Cz[(long)i * ldc + j] = v;
             cmax = fmaxf(cmax, fabsf(v));
         }
     }
@@ -364,9 +369,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
     }
 }
 
-#ifdef GEMM_STAMPS
-static int gemm_launch_seq = 0;
-#endif
 struct GemmLaunch {
     GemmBatch b;
     int blocks = 0;
@@ -456,7 +458,17 @@ struct AwArgs {
     int nseg, lda, M, N;                 // every product has N columns
     AwProduct p[3];
     int nprod;
+    int launch_seq;                      // debug builds: number of the launch
 };
+#ifdef GEMM_STAMPS
+#define ASTAMP(i)                                                                                                           \
+    do {                                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < GEMM_STAMP_WGS)                                                                \
+            gemm_stamp_buf[((size_t)(a.launch_seq & 63) * GEMM_STAMP_WGS + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ASTAMP(i)
+#endif
 
 // B(k, j) = W[j * ld + k] (transposed == 0: Y = X W^T) or W[k * ld + j] (transposed: dX = dY W), Kd x Jd
 struct PackItem {
@@ -502,12 +514,16 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
     constexpr int LDA = K + 8, CH = K / 128, NL = (32 * K / 4) / 256;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
+    ASTAMP(0);
     const int tpp = a.N / 128;                                // tiles per wave and product
     const int G = a.nprod * tpp * a.nseg * CH;                // chunks of eight k-steps this wave walks through
     // the wave's B operands of chunk g: 16 KB of consecutive addresses
     auto chunk_ptr = [&](int g) {
         const int c = g % CH, seg = (g / CH) % a.nseg, tile = g / (CH * a.nseg);
         const int jt = w + 4 * (tile % tpp);
+#ifdef AW_SAME_CHUNK
+        return reinterpret_cast<const u32x4 *>(a.p[0].Bp[0]) + lane;     // (timing experiment: one L1-resident chunk for every wave)
+#endif
         return reinterpret_cast<const u32x4 *>(a.p[tile / tpp].Bp[seg]) + ((long)(jt * (K / 16) + 8 * c) * 2) * 64 + lane;
     };
     u32x4 b0[16], b1[16];
@@ -527,8 +543,8 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
 #pragma unroll
                 for (int e = 0; e < NL; ++e) {
                     const int idx = tid + 256 * e, row = idx / (K / 4), c4 = idx % (K / 4);
-                    v[seg * NL + e] = i0 + row < a.M ? *reinterpret_cast<const float4 *>(a.A[seg] + (long)(i0 + row) * a.lda + 4 * c4)
-                                                     : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                    const int rr = min(i0 + row, a.M - 1);            // (rows beyond M: a valid address, scaled by zero below)
+                    v[seg * NL + e] = *reinterpret_cast<const float4 *>(a.A[seg] + (long)rr * a.lda + 4 * c4);
                 }
             }
         }
@@ -538,6 +554,11 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
         for (int seg = 0; seg < nsegs; ++seg)
             if (a.amax_a[seg]) { bound = fmaxf(bound, amax_read(a.amax_a[seg])); scaled = true; }
         if (scaled) sa = pow2_scale_for(bound);
+        ASTAMP(1);
+#ifdef GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ASTAMP(2);
+#endif
 #pragma unroll
         for (int seg = 0; seg < (K == 128 ? AW_SEGS : 1); ++seg) {
             if (seg < nsegs) {
@@ -546,20 +567,23 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
                 for (int e = 0; e < NL; ++e) {
                     const int idx = tid + 256 * e, row = idx / (K / 4), c4 = idx % (K / 4);
                     const float4 x = v[seg * NL + e];
+                    const float sr = i0 + row < a.M ? sa : 0.0f;
                     unsigned h0, l0, h1, l1;
-                    split2(x.x * sa, x.y * sa, h0, l0);
-                    split2(x.z * sa, x.w * sa, h1, l1);
+                    split2(x.x * sr, x.y * sr, h0, l0);
+                    split2(x.z * sr, x.w * sr, h1, l1);
                     *reinterpret_cast<u32x2 *>(H + row * LDA + 4 * c4) = u32x2{h0, h1};
                     *reinterpret_cast<u32x2 *>(L + row * LDA + 4 * c4) = u32x2{l0, l1};
                 }
             }
         }
     }
+    ASTAMP(3);
     __syncthreads();
+    ASTAMP(4);
     const float unscale = 1.0f / sa;
     const bool full_rows = i0 + 32 <= a.M;
     f32x16 acc = zero16();
-    float other[16], gate[16], bias_j = 0.0f;
+    float other[16], gate[16], bias_j = 0.0f, pmax[3] = {0.0f, 0.0f, 0.0f};
     // one chunk: eight k-steps from registers `b`, the next chunk's loads issued first
     auto chunk = [&](int g, u32x4 (&b)[16], u32x4 (&bn)[16]) {
         if (g + 1 < G) load_chunk(bn, g + 1);
@@ -606,36 +630,58 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
             acc = MFMA16(ah, bl, acc);
             acc = MFMA16(ah, bh, acc);
         }
+#ifdef GEMM_STAMPS
+        if (last && tile < 4) ASTAMP(5 + 2 * tile);
+#endif
         if (last) {
+            // (the product's fields in registers before the first store: after a store through a float pointer the
+            // compiler re-reads every field it needs from the argument segment, one scalar round trip each)
+            float *const C = P.C;
+            const int ldc = P.ldc, rows = a.M;
+            const bool plain = P.mode == 0, relu = P.relu != 0;
             float cmax = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!full_rows && i >= a.M) continue;
+                if (!full_rows && i >= rows) continue;
                 float v = acc[r] * unscale;
-                if (P.mode == 0) {
+                if (plain) {
                     v += bias_j;
-                    if (P.relu) v = fmaxf(v, 0.0f);
+                    if (relu) v = fmaxf(v, 0.0f);
                     if (!(gate[r] > 0.0f)) v = 0.0f;
                 }
                 v = other[r] + v;
-                P.C[(long)i * P.ldc + j] = v;
+                C[(long)i * ldc + j] = v;
                 cmax = fmaxf(cmax, fabsf(v));
             }
-            if (P.amax_c) {
-                cmax = wave_max_f32(cmax);
-                if (lane == 0) atomic_max_abs(P.amax_c, cmax);
-            }
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi)
+                if (pi == tile / tpp) pmax[pi] = fmaxf(pmax[pi], cmax);
+#ifdef GEMM_STAMPS
+            if (tile < 4) ASTAMP(6 + 2 * tile);
+#endif
         }
     };
     for (int g = 0; g < G; g += 2) {
         chunk(g, b0, b1);
         if (g + 1 < G) chunk(g + 1, b1, b0);
     }
+    // the products' magnitude bounds, once per wave: the read-before-atomic waits for every store issued so far
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        if (pi < a.nprod && a.p[pi].amax_c) {
+            const float m = wave_max_f32(pmax[pi]);
+            if (lane == 0) atomic_max_abs(a.p[pi].amax_c, m);
+        }
+    }
+    ASTAMP(13);
 }
 static size_t aw_lds_bytes(int K, int nseg) { return (size_t)nseg * 2 * 32 * (K + 8) * 2; }
-static void launch_aw(hipStream_t s, const AwArgs &a, int K) {
+static void launch_aw(hipStream_t s, AwArgs a, int K) {
     const int blocks = (a.M + 31) / 32;
+#ifdef GEMM_STAMPS
+    a.launch_seq = gemm_launch_seq++;
+#endif
     if (K == 128) {
         hipLaunchKernelGGL(gemm_aw_kernel<128>, dim3(blocks), dim3(256), aw_lds_bytes(128, a.nseg), s, a);
     } else {
@@ -735,15 +781,12 @@ __global__ void gather_tile_kernel(const float *__restrict__ tile, int row_strid
 __device__ __forceinline__ int rm_off(int row, int blk) { return row * 16 + ((blk ^ ((row >> 2) & 1)) << 3); }
 #define ATT_TS(NT) (32 * (NT) + 4)
 
-// exp(x) for x <= 0 with the rounding error of x * log2(e) compensated (v_exp_f32 alone would lose |x| * 1e-7)
-__device__ __forceinline__ float exp_neg(float x) {
-    if (!(x > -100.0f)) return 0.0f;
-    const float L2E = 1.44269502f, L2E_LO = 1.92596299e-8f;
-    const float t = x * L2E;
-    const float lo = fmaf(x, L2E, -t) + x * L2E_LO;
-    const float e = __builtin_amdgcn_exp2f(t);
-    return fmaf(e, lo * 0.693147182f, e);
-}
+// Scores are kept in the base-2 domain: s2 = (q.k / 4) log2(e), the row statistics are max_j s2 and
+// sum_j 2^(s2 - max), and a probability is one FMA (the raw accumulator times a constant, minus the maximum) and one
+// v_exp_f32.  The rounding of that FMA's result, 2^-24 of |s2 - max|, is the error the subtraction s - max of a
+// natural-base softmax carries too.
+#define LOG2E 1.44269502f
+__device__ __forceinline__ float exp2_neg(float t) { return __builtin_amdgcn_exp2f(t); }      // 0 for t = -inf
 
 // stages head hd of src rows tok0 .. tok0 + n - 1 (times scale) into the images that are given (else nullptr)
 __device__ __forceinline__ void stage_head_split(const float *__restrict__ src, long tok0, int n, int n_pad, int hd, float scale,
@@ -858,24 +901,25 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
     f16x8 qh, ql;
     split8(qv, sq, qh, ql);
     __syncthreads();
-    const float cs = 0.25f / (sq * sk);
+    const float cs = 0.25f * LOG2E / (sq * sk);
     // one pass over the key tiles with a running maximum: whenever it grows, the sum and the output accumulated so
-    // far are rescaled (exp(old - new) <= 1).  Equal to softmax(s) V up to rounding.
+    // far are rescaled (2^(old - new) <= 1).  Equal to softmax(s) V up to rounding.
     float mx = -INFINITY, sum = 0.0f;
     f32x16 o = zero16();
     for (int jt = 0; jt < NT; ++jt) {
         const int ko = rm_off(32 * jt + q, h);
         f32x16 sc = mfma_split(*reinterpret_cast<const f16x8 *>(Kh + ko), *reinterpret_cast<const f16x8 *>(Kl + ko), qh, ql, zero16());
-        float tmax = -INFINITY;
+        if (32 * jt + 32 > n) {                          // the last tile: keys beyond n drop out
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int j = 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
-            sc[e] = j < n ? sc[e] * cs : -INFINITY;
-            tmax = fmaxf(tmax, sc[e]);
+            for (int e = 0; e < 16; ++e)
+                if (32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h >= n) sc[e] = -INFINITY;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        float tmax = sc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * cs;           // cs > 0: the maximum commutes with the scaling
         if (tmax > mx) {
-            const float f = exp_neg(mx - tmax);          // 0 on the first tile (mx = -inf)
+            const float f = exp2_neg(mx - tmax);         // 0 on the first tile (mx = -inf)
             sum *= f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[e] *= f;
@@ -883,7 +927,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            sc[e] = exp_neg(sc[e] - mx);
+            sc[e] = exp2_neg(fmaf(sc[e], cs, -mx));
             sum += sc[e];
         }
 #pragma unroll
@@ -949,7 +993,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float *__restrict
         inv = 1.0f / st[1];
     }
     __syncthreads();
-    const float cs = 0.25f / (sq * sk), cg = 1.0f / (sv * sg);
+    const float cs = 0.25f * LOG2E / (sq * sk), cg = 1.0f / (sv * sg);
     f32x16 dq = zero16();
     for (int jt = 0; jt < NT; ++jt) {
         const int ko = rm_off(32 * jt + q, h);
@@ -957,9 +1001,13 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float *__restrict
         const f32x16 dp = mfma_split(*reinterpret_cast<const f16x8 *>(Vh + ko), *reinterpret_cast<const f16x8 *>(Vl + ko), gh, gl, zero16());
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int j = 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float p = j < n ? exp_neg(sc[e] * cs - mx) * inv : 0.0f;
+            const float p = exp2_neg(fmaf(sc[e], cs, -mx)) * inv;
             sc[e] = p * (dp[e] * cg - dt) * 0.25f;                              // dS[i][j]
+        }
+        if (32 * jt + 32 > n) {                          // the last tile: keys beyond n drop out
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h >= n) sc[e] = 0.0f;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1025,7 +1073,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float *__restric
     split8(vv, sv, vh, vl);
     __syncthreads();
     const float c = pow2_scale_for(__uint_as_float(*bound_bits));
-    const float cs = 0.25f / (sq * sk), cg = 1.0f / (sv * sg);
+    const float cs = 0.25f * LOG2E / (sq * sk), cg = 1.0f / (sv * sg);
     f32x16 dk = zero16(), dv = zero16();
     for (int it = 0; it < NT; ++it) {
         const int qo = rm_off(32 * it + q, h);
@@ -1039,7 +1087,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float *__restric
             const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {v4.x, v4.y, v4.z, v4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = exp_neg(sc[4 * g4 + e] * cs - mm[e]) * ii[e];
+                const float p = exp2_neg(fmaf(sc[4 * g4 + e], cs, -mm[e])) * ii[e];
                 sc[4 * g4 + e] = p;                                               // P[i][j]
                 dp[4 * g4 + e] = p * (dp[4 * g4 + e] * cg - dd[e]) * 0.25f;       // dS[i][j]
             }

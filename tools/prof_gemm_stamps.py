@@ -33,6 +33,17 @@ buf = buf.reshape(64, WGS, 16).astype(np.int64)
 names = ["start", "loads+stage0", "barrier", "rest of K", "epilogue", "amax"]
 for L in range(64):
     b = buf[L]
+    if (b[:, 13] > 0).any():         # an activation x weight launch
+        s = b[b[:, 13] > 0]
+        d = np.diff(s[:, :14], axis=1)
+        nm = ["issue loads+scales", "wait A", "split+LDS", "barrier", "tile0 MFMA", "tile0 epilogue", "tile1 MFMA", "tile1 epi",
+              "tile2 MFMA", "tile2 epi", "tile3 MFMA", "tile3 epi", "tail"]
+        used = [i for i in range(13) if (s[:, i + 1] > 0).all() and (s[:, i] > 0).all()]
+        print(f"launch slot {L} (activation x weight): {len(s)} workgroups, per-workgroup total median {np.median(s[:, 13] - s[:, 0]):.0f}")
+        print("    " + "  ".join(f"{nm[i]} {np.median(d[:, i]):.0f}" for i in used))
+        last = max(i for i in range(13) if (s[:, i] > 0).all())
+        print(f"    last tile stamp -> end: {np.median(s[:, 13] - s[:, last]):.0f}")
+        continue
     live = (b[:, 0] > 0) & (b[:, 6] > b[:, 0])
     if not live.any():
         continue
