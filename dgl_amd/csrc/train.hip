@@ -35,7 +35,7 @@ __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f
 //   mode 0: C = acc (+ bias[j]) (ReLU) (+ add[i][j]);  mode 1: C += acc;
 //   mode 3: C + z * part_stride = acc of K-chunk z (partial products, summed in fixed order by reduce_partials_kernel:
 //           no float atomics anywhere, results are bit-reproducible)
-#define GEMM_SEGS 3
+#define GEMM_SEGS 1      // (products of several segments run in the activation x weight kernel)
 struct GemmArgs {
     const float *A[GEMM_SEGS], *B[GEMM_SEGS];
     const float *amax_a[GEMM_SEGS];   // per segment: bound of |A_s| (device scalar) or NULL = unscaled
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
     auto chunk = [&](int g, u32x4 (&b)[16], u32x4 (&bn)[16]) {
         if (g + 1 < G) load_chunk(bn, g + 1);
         const int c = g % CH, seg = (g / CH) % a.nseg, tile = g / (CH * a.nseg);
-        const AwProduct &P = a.p[tile / tpp];
+        const AwProduct P = a.p[tile / tpp];          // (a copy in registers: a reference is re-read field by field after every store)
         const int j = 32 * (w + 4 * (tile % tpp)) + q;
         const bool last = c == CH - 1 && seg == a.nseg - 1;
         if (c == 0 && seg == 0) acc = zero16();
