@@ -1160,19 +1160,21 @@ __global__ __launch_bounds__(128) void anchor_bwd_kernel(float *__restrict__ dY,
 // Per row: logits = X wf + bf, masking, softmax, floor (TSP/TSPModel.py:312-326,
 // CVRP/CVRPModel.py:462-493), the outputs of dgl_policy_forward, and for training the teacher's
 // probability (1e-20 when the teacher's action is not a candidate, as in the dense tensor the
-// reference indexes) and dX = d(-mean log p_teacher)/dX, dwf, dbf.  One wave per row.
-__global__ __launch_bounds__(64) void output_kernel(const float *__restrict__ X, const float *__restrict__ wf,
-                                                    const float *__restrict__ bf, dgl_policy_io_t io,
-                                                    const int32_t *__restrict__ teacher, float grad_scale,
-                                                    float *__restrict__ teacher_prob, float *__restrict__ dX,
-                                                    float *__restrict__ dwf_part,      // [R][128]: row r's term of dwf
-                                                    float *__restrict__ dbf_part,      // [R]
-                                                    float *__restrict__ amax_dx) {
-    extern __shared__ float lg[];              // [n] logits, then probabilities
-    const int r = blockIdx.x, lane = threadIdx.x, n = io.n;
+// reference indexes) and dX = d(-mean log p_teacher)/dX, dwf, dbf.  One workgroup of four waves per row.
+__global__ __launch_bounds__(256) void output_kernel(const float *__restrict__ X, const float *__restrict__ wf,
+                                                     const float *__restrict__ bf, dgl_policy_io_t io,
+                                                     const int32_t *__restrict__ teacher, float grad_scale,
+                                                     float *__restrict__ teacher_prob, float *__restrict__ dX,
+                                                     float *__restrict__ dwf_part,      // [R][128]: row r's term of dwf
+                                                     float *__restrict__ dbf_part,      // [R]
+                                                     float *__restrict__ amax_dx) {
+    extern __shared__ float lg[];              // [n] logits, then probabilities, then logit gradients; [256] partial dwf
+    __shared__ int s_teacher;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = io.n;
     const int stride = io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS;
     const int anchor0 = io.k_last, anchor1 = n - 1;
     const float *xr = X + (long)r * n * D_MODEL;
+    float *dw_half = lg + n;
     auto is_cand = [&](int t) { return t != anchor0 && t != anchor1; };
     auto is_open = [&](int t) {
         if (!is_cand(t)) return false;
@@ -1184,85 +1186,104 @@ __global__ __launch_bounds__(64) void output_kernel(const float *__restrict__ X,
         if (io.problem == DGL_PROBLEM_TSP || t < io.k_last) return io.idx_last[(size_t)r * io.idx_stride + t];
         return io.idx_depot[(size_t)r * io.idx_dep_stride + (t - io.k_last - 1)] + io.N + 1;
     };
-    float mx = -INFINITY;
-    for (int t = lane; t < n; t += 64) {
-        float s = 0.0f;
-        for (int c = 0; c < D_MODEL; ++c) s = fmaf(xr[t * D_MODEL + c], wf[c], s);
-        s += bf[0];
-        lg[t] = s;
-        if (io.logits_out) io.logits_out[(size_t)r * stride + t] = s;
-        if (is_open(t)) mx = fmaxf(mx, s);
-    }
-    mx = wave_max_f32(mx);
-    float sum = 0.0f;
-    for (int t = lane; t < n; t += 64) {
-        const float e = is_open(t) ? expf(lg[t] - mx) : 0.0f;
-        lg[t] = e;
-        sum += e;
-    }
+    // logits: a wave per token, two columns per lane, the 64 partial products added as a fixed tree
+    {
+        const float2 w2 = {wf[2 * lane], wf[2 * lane + 1]};
+        const float b = bf[0];
+        for (int t = wave; t < n; t += 4) {
+            const float2 x2 = *reinterpret_cast<const float2 *>(xr + t * D_MODEL + 2 * lane);
+            float sum = fmaf(x2.y, w2.y, x2.x * w2.x);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    float best = -1.0f;
-    int best_act = 0x7FFFFFFF, t_teacher = -1;
-    const int want = teacher ? teacher[r] : -1;
-    for (int t = lane; t < n; t += 64) {
-        const float p = lg[t] / sum;                 // pure softmax (kept for the gradient)
-        lg[t] = p;
-        float pf = p;
-        if (pf <= 1e-5f) pf = pf + 1e-7f;
-        if (!is_cand(t)) pf = 0.0f;
-        if (io.prob_out) io.prob_out[(size_t)r * stride + t] = pf;
-        if (is_cand(t)) {
-            const int act = action(t);
-            if (pf > best || (pf == best && act < best_act)) { best = pf; best_act = act; }
-            if (act == want) t_teacher = t;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            sum += b;
+            if (lane == 0) {
+                lg[t] = sum;
+                if (io.logits_out) io.logits_out[(size_t)r * stride + t] = sum;
+            }
         }
     }
-    // greedy pick: highest probability, lowest action id on ties
-    float wbest = wave_max_f32(best);
-    int cand_act = (best == wbest) ? best_act : 0x7FFFFFFF;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cand_act = min(cand_act, __shfl_xor(cand_act, o, 64));
-    if (lane == 0 && io.selected_out) io.selected_out[r] = cand_act;
-    if (!teacher) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t_teacher = max(t_teacher, __shfl_xor(t_teacher, o, 64));
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    float pt = 1e-20f, g_logit_scale = 0.0f, p_soft = 0.0f;
-    if (t_teacher >= 0) {
-        p_soft = lg[t_teacher];
-        pt = p_soft <= 1e-5f ? p_soft + 1e-7f : p_soft;
-        // L = -grad_scale^-1... : dL/dp_t = -grad_scale / p_t (grad_scale = 1 / rows of the global batch)
-        g_logit_scale = -grad_scale / pt;
-    }
-    if (lane == 0 && teacher_prob) teacher_prob[r] = pt;
-    if (!dX) return;
-    float dbsum = 0.0f;
-    for (int t = lane; t < n; t += 64) {
-        // d p_t / d logit_j = p_t (delta_tj - p_j) over the open tokens
-        float dl = 0.0f;
-        if (t_teacher >= 0 && is_open(t)) dl = g_logit_scale * p_soft * ((t == t_teacher ? 1.0f : 0.0f) - lg[t]);
-        lg[t] = dl;
-        dbsum += dl;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dbsum += __shfl_xor(dbsum, o, 64);
-    if (lane == 0) dbf_part[r] = dbsum;
-    float gmax = 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < D_MODEL; c += 64) {
-        float dw = 0.0f;
-        const float w = wf[c];
-        for (int t = 0; t < n; ++t) {
-            const float dl = lg[t];
-            dX[((long)r * n + t) * D_MODEL + c] = dl * w;
-            gmax = fmaxf(gmax, fabsf(dl * w));
-            dw = fmaf(dl, xr[t * D_MODEL + c], dw);
+    __syncthreads();
+    const bool train = teacher != nullptr;
+    float pt = 1e-20f;
+    if (wave == 0) {
+        // masking, softmax, floor, greedy pick and the teacher's probability: one wave
+        float mx = -INFINITY;
+        for (int t = lane; t < n; t += 64)
+            if (is_open(t)) mx = fmaxf(mx, lg[t]);
+        mx = wave_max_f32(mx);
+        float sum = 0.0f;
+        for (int t = lane; t < n; t += 64) {
+            const float e = is_open(t) ? expf(lg[t] - mx) : 0.0f;
+            lg[t] = e;
+            sum += e;
         }
-        dwf_part[(long)r * D_MODEL + c] = dw;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        float best = -1.0f;
+        int best_act = 0x7FFFFFFF, t_teacher = -1;
+        const int want = train ? teacher[r] : -1;
+        for (int t = lane; t < n; t += 64) {
+            const float p = lg[t] / sum;                 // pure softmax (kept for the gradient)
+            lg[t] = p;
+            float pf = p;
+            if (pf <= 1e-5f) pf = pf + 1e-7f;
+            if (!is_cand(t)) pf = 0.0f;
+            if (io.prob_out) io.prob_out[(size_t)r * stride + t] = pf;
+            if (is_cand(t)) {
+                const int act = action(t);
+                if (pf > best || (pf == best && act < best_act)) { best = pf; best_act = act; }
+                if (act == want) t_teacher = t;
+            }
+        }
+        // greedy pick: highest probability, lowest action id on ties
+        const float wbest = wave_max_f32(best);
+        int cand_act = (best == wbest) ? best_act : 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand_act = min(cand_act, __shfl_xor(cand_act, o, 64));
+        if (lane == 0 && io.selected_out) io.selected_out[r] = cand_act;
+        if (train) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t_teacher = max(t_teacher, __shfl_xor(t_teacher, o, 64));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            float g_logit_scale = 0.0f, p_soft = 0.0f;
+            if (t_teacher >= 0) {
+                p_soft = lg[t_teacher];
+                pt = p_soft <= 1e-5f ? p_soft + 1e-7f : p_soft;
+                // L = -mean log p_teacher: dL/dp_t = -grad_scale / p_t (grad_scale = 1 / rows of the global batch)
+                g_logit_scale = -grad_scale / pt;
+            }
+            if (lane == 0 && teacher_prob) teacher_prob[r] = pt;
+            if (dX) {
+                float dbsum = 0.0f;
+                for (int t = lane; t < n; t += 64) {
+                    // d p_t / d logit_j = p_t (delta_tj - p_j) over the open tokens
+                    float dl = 0.0f;
+                    if (t_teacher >= 0 && is_open(t)) dl = g_logit_scale * p_soft * ((t == t_teacher ? 1.0f : 0.0f) - lg[t]);
+                    lg[t] = dl;
+                    dbsum += dl;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dbsum += __shfl_xor(dbsum, o, 64);
+                if (lane == 0) dbf_part[r] = dbsum;
+            }
+        }
     }
+    if (!train || !dX) return;
+    __syncthreads();
+    // dX = dlogit wf^T and row r's term of dwf = sum_t dlogit_t x_t: thread = (column, half of the tokens)
+    const int c = tid & (D_MODEL - 1), half = tid >> 7;
+    const float w = wf[c];
+    float dw = 0.0f, gmax = 0.0f;
+    for (int t = half; t < n; t += 2) {
+        const float dl = lg[t];
+        dX[((long)r * n + t) * D_MODEL + c] = dl * w;
+        gmax = fmaxf(gmax, fabsf(dl * w));
+        dw = fmaf(dl, xr[t * D_MODEL + c], dw);
+    }
+    dw_half[tid] = dw;
+    __syncthreads();
+    if (half == 0) dwf_part[(long)r * D_MODEL + c] = dw_half[c] + dw_half[D_MODEL + c];
     gmax = wave_max_f32(gmax);
     if (lane == 0) atomic_max_abs(amax_dx, gmax);
 }
@@ -1500,7 +1521,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         dwf_part = ps.take((float *)grad->final_w, R, D_MODEL);
         dbf_part = ps.take((float *)grad->final_b, R, 1);
     }
-    hipLaunchKernelGGL(output_kernel, dim3(R), dim3(64), (size_t)n * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
+    hipLaunchKernelGGL(output_kernel, dim3(R), dim3(256), (size_t)(n + 256) * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
                        teacher, grad_scale, teacher_prob_out, train ? dA : nullptr, dwf_part, dbf_part, bound(AX_DX + 4));
     DGL_CHECK_LAUNCH("dgl_policy_general (forward)");
     if (!train) return DGL_OK;
