@@ -1168,71 +1168,112 @@ __global__ __launch_bounds__(256) void output_kernel(const float *__restrict__ X
                                                      float *__restrict__ dwf_part,      // [R][128]: row r's term of dwf
                                                      float *__restrict__ dbf_part,      // [R]
                                                      float *__restrict__ amax_dx) {
-    extern __shared__ float lg[];              // [n] logits, then probabilities, then logit gradients; [256] partial dwf
+    extern __shared__ __align__(16) float xs[]; // [n][129]: the row's final hidden states (odd stride: a thread per token
+                                                // reads down its row without bank conflicts); then lg and the partial dwf
+    constexpr int XS = D_MODEL + 1;
+    float *lg = xs + (size_t)io.n * XS;         // [n] logits, then probabilities, then logit gradients; [256] partial dwf
     __shared__ int s_teacher;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = io.n;
     const int stride = io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS;
     const int anchor0 = io.k_last, anchor1 = n - 1;
+    // (the descriptor's fields in registers: after a store the compiler re-reads from the argument segment whatever
+    // it needs of a by-value struct, one scalar round trip per use)
+    float *const logits_out = io.logits_out, *const prob_out = io.prob_out;
+    int32_t *const selected_out = io.selected_out;
+    const uint8_t *const infeasible = io.infeasible;
+    const int32_t *const idx_last = io.idx_last, *const idx_depot = io.idx_depot;
+    const int idx_stride = io.idx_stride, idx_dep_stride = io.idx_dep_stride, k_last = io.k_last, n_nodes = io.N;
+    const bool cvrp = io.problem == DGL_PROBLEM_CVRP;
     const float *xr = X + (long)r * n * D_MODEL;
     float *dw_half = lg + n;
     auto is_cand = [&](int t) { return t != anchor0 && t != anchor1; };
     auto is_open = [&](int t) {
         if (!is_cand(t)) return false;
-        if (io.problem == DGL_PROBLEM_CVRP && io.infeasible != nullptr && t < io.k_last)
-            return io.infeasible[(size_t)r * io.idx_stride + t] == 0;
+        if (cvrp && infeasible != nullptr && t < k_last) return infeasible[(size_t)r * idx_stride + t] == 0;
         return true;
     };
     auto action = [&](int t) {
-        if (io.problem == DGL_PROBLEM_TSP || t < io.k_last) return io.idx_last[(size_t)r * io.idx_stride + t];
-        return io.idx_depot[(size_t)r * io.idx_dep_stride + (t - io.k_last - 1)] + io.N + 1;
+        if (!cvrp || t < k_last) return idx_last[(size_t)r * idx_stride + t];
+        return idx_depot[(size_t)r * idx_dep_stride + (t - k_last - 1)] + n_nodes + 1;
     };
-    // logits: a wave per token, two columns per lane, the 64 partial products added as a fixed tree
+    // the row's hidden states into LDS, sixteen 16-byte loads in flight per thread (64 workgroups cannot hide
+    // memory latency behind each other: every dependent round trip to memory counts in full)
     {
-        const float2 w2 = {wf[2 * lane], wf[2 * lane + 1]};
-        const float b = bf[0];
-        for (int t = wave; t < n; t += 4) {
-            const float2 x2 = *reinterpret_cast<const float2 *>(xr + t * D_MODEL + 2 * lane);
-            float sum = fmaf(x2.y, w2.y, x2.x * w2.x);
+        const float4 *src = reinterpret_cast<const float4 *>(xr);
+        const int total = n * (D_MODEL / 4);
+        for (int e0 = tid; e0 < total; e0 += 16 * 256) {
+            float4 v[16];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            sum += b;
-            if (lane == 0) {
-                lg[t] = sum;
-                if (io.logits_out) io.logits_out[(size_t)r * stride + t] = sum;
+            for (int u = 0; u < 16; ++u) v[u] = src[min(e0 + 256 * u, total - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + 256 * u;
+                if (e < total) {
+                    float *d = xs + (e >> 5) * XS + (e & 31) * 4;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
             }
         }
+        if (tid < D_MODEL) lg[n + tid] = wf[tid];                   // (the partial-dwf area holds wf until the logits are done)
+    }
+    __syncthreads();
+    // logits: a thread per token, columns in order (one FMA chain, as the fused decode kernels' final layer)
+    if (tid < n) {
+        const float *x = xs + tid * XS, *wv = lg + n;
+        float sum = 0.0f;
+#pragma unroll 16
+        for (int c = 0; c < D_MODEL; ++c) sum = fmaf(x[c], wv[c], sum);
+        sum += bf[0];
+        lg[tid] = sum;
+        if (logits_out) logits_out[(size_t)r * stride + tid] = sum;
     }
     __syncthreads();
     const bool train = teacher != nullptr;
     float pt = 1e-20f;
     if (wave == 0) {
-        // masking, softmax, floor, greedy pick and the teacher's probability: one wave
-        float mx = -INFINITY;
-        for (int t = lane; t < n; t += 64)
-            if (is_open(t)) mx = fmaxf(mx, lg[t]);
+        // masking, softmax, floor, greedy pick and the teacher's probability: one wave, four tokens per lane
+        // (n <= 256), each token's mask bit and action id fetched once, all of them in flight together
+        bool cand[4], open[4];
+        int act[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = lane + 64 * u;
+            cand[u] = t < n && is_cand(t);
+            open[u] = t < n && is_open(t);
+            act[u] = cand[u] ? action(t) : 0x7FFFFFFF;
+        }
+        float v[4], mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = lane + 64 * u < n ? lg[lane + 64 * u] : 0.0f;
+            if (open[u]) mx = fmaxf(mx, v[u]);
+        }
         mx = wave_max_f32(mx);
         float sum = 0.0f;
-        for (int t = lane; t < n; t += 64) {
-            const float e = is_open(t) ? expf(lg[t] - mx) : 0.0f;
-            lg[t] = e;
-            sum += e;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = open[u] ? expf(v[u] - mx) : 0.0f;
+            sum += v[u];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         float best = -1.0f;
         int best_act = 0x7FFFFFFF, t_teacher = -1;
         const int want = train ? teacher[r] : -1;
-        for (int t = lane; t < n; t += 64) {
-            const float p = lg[t] / sum;                 // pure softmax (kept for the gradient)
-            lg[t] = p;
-            float pf = p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = lane + 64 * u;
+            v[u] = v[u] / sum;                           // pure softmax (kept for the gradient)
+            float pf = v[u];
             if (pf <= 1e-5f) pf = pf + 1e-7f;
-            if (!is_cand(t)) pf = 0.0f;
-            if (io.prob_out) io.prob_out[(size_t)r * stride + t] = pf;
-            if (is_cand(t)) {
-                const int act = action(t);
-                if (pf > best || (pf == best && act < best_act)) { best = pf; best_act = act; }
-                if (act == want) t_teacher = t;
+            if (!cand[u]) pf = 0.0f;
+            if (t < n) {
+                lg[t] = v[u];
+                if (prob_out) prob_out[(size_t)r * stride + t] = pf;
+            }
+            if (cand[u]) {
+                if (pf > best || (pf == best && act[u] < best_act)) { best = pf; best_act = act[u]; }
+                if (act[u] == want) t_teacher = t;
             }
         }
         // greedy pick: highest probability, lowest action id on ties
@@ -1240,7 +1281,7 @@ __global__ __launch_bounds__(256) void output_kernel(const float *__restrict__ X
         int cand_act = (best == wbest) ? best_act : 0x7FFFFFFF;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cand_act = min(cand_act, __shfl_xor(cand_act, o, 64));
-        if (lane == 0 && io.selected_out) io.selected_out[r] = cand_act;
+        if (lane == 0 && selected_out) selected_out[r] = cand_act;
         if (train) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) t_teacher = max(t_teacher, __shfl_xor(t_teacher, o, 64));
@@ -1256,11 +1297,13 @@ __global__ __launch_bounds__(256) void output_kernel(const float *__restrict__ X
             if (lane == 0 && teacher_prob) teacher_prob[r] = pt;
             if (dX) {
                 float dbsum = 0.0f;
-                for (int t = lane; t < n; t += 64) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = lane + 64 * u;
                     // d p_t / d logit_j = p_t (delta_tj - p_j) over the open tokens
                     float dl = 0.0f;
-                    if (t_teacher >= 0 && is_open(t)) dl = g_logit_scale * p_soft * ((t == t_teacher ? 1.0f : 0.0f) - lg[t]);
-                    lg[t] = dl;
+                    if (t_teacher >= 0 && open[u]) dl = g_logit_scale * p_soft * ((t == t_teacher ? 1.0f : 0.0f) - v[u]);
+                    if (t < n) lg[t] = dl;
                     dbsum += dl;
                 }
 #pragma unroll
@@ -1275,11 +1318,14 @@ __global__ __launch_bounds__(256) void output_kernel(const float *__restrict__ X
     const int c = tid & (D_MODEL - 1), half = tid >> 7;
     const float w = wf[c];
     float dw = 0.0f, gmax = 0.0f;
+    // (loads and stores in separate loops: interleaved, every load would wait behind the store before it)
+#pragma unroll 8
+    for (int t = half; t < n; t += 2) dw = fmaf(lg[t], xs[t * XS + c], dw);
+#pragma unroll 8
     for (int t = half; t < n; t += 2) {
-        const float dl = lg[t];
-        dX[((long)r * n + t) * D_MODEL + c] = dl * w;
-        gmax = fmaxf(gmax, fabsf(dl * w));
-        dw = fmaf(dl, xr[t * D_MODEL + c], dw);
+        const float g = lg[t] * w;
+        dX[((long)r * n + t) * D_MODEL + c] = g;
+        gmax = fmaxf(gmax, fabsf(g));
     }
     dw_half[tid] = dw;
     __syncthreads();
@@ -1521,7 +1567,8 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         dwf_part = ps.take((float *)grad->final_w, R, D_MODEL);
         dbf_part = ps.take((float *)grad->final_b, R, 1);
     }
-    hipLaunchKernelGGL(output_kernel, dim3(R), dim3(256), (size_t)(n + 256) * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
+    (void)hipFuncSetAttribute((const void *)output_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (256 * (D_MODEL + 1) + 512) * (int)sizeof(float));
+    hipLaunchKernelGGL(output_kernel, dim3(R), dim3(256), ((size_t)n * (D_MODEL + 1) + n + 256) * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
                        teacher, grad_scale, teacher_prob_out, train ? dA : nullptr, dwf_part, dbf_part, bound(AX_DX + 4));
     DGL_CHECK_LAUNCH("dgl_policy_general (forward)");
     if (!train) return DGL_OK;
