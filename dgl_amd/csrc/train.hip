@@ -329,13 +329,13 @@ static inline __host__ __device__ int gemm_blocks(const GemmArgs &g) {
     return zs > 1 ? gx * gy * gemm_round8(zs) : gemm_round8(gx) * gy;
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
+__device__ __forceinline__ void gemm_batch_block(const GemmBatch &batch, const int block) {
     extern __shared__ __align__(16) _Float16 gemm_lds[];
     int b = 0;
-    while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
+    while (b + 1 < batch.count && block >= batch.first[b + 1]) ++b;
     const GemmArgs &g = batch.g[b];
     GSTAMP(0);
-    const int local = blockIdx.x - batch.first[b];
+    const int local = block - batch.first[b];
     const int gx = (g.I + 63) / 64, gy = (g.J + 63) / 64, zs = (g.KK + g.kchunk - 1) / g.kchunk;
     int ti, tj, z;
     if (zs > 1) {
@@ -368,6 +368,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) {
         else gemm_tile<false, false, false>(g, i0, j0, z, gemm_lds);
     }
 }
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch) { gemm_batch_block(batch, blockIdx.x); }
 
 struct GemmLaunch {
     GemmBatch b;
@@ -482,7 +484,10 @@ struct PackBatch {
     int first[PACK_ITEMS_MAX + 1];       // first workgroup of each item
     int count;
 };
-__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch batch) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch batch, float *__restrict__ zero, int zero_count) {
+    // (the call's first launch also clears the magnitude bounds)
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < zero_count) zero[gid] = 0.0f;
     int b = 0;
     while (b + 1 < batch.count && (int)blockIdx.x >= batch.first[b + 1]) ++b;
     const PackItem &it = batch.it[b];
@@ -509,11 +514,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch batch) {
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
+__device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) {
     extern __shared__ __align__(16) _Float16 aw_lds[];       // [nseg][hi, lo][32][K + 8]
     constexpr int LDA = K + 8, CH = K / 128, NL = (32 * K / 4) / 256;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
-    const int i0 = blockIdx.x * 32;
+    const int i0 = block * 32;
     ASTAMP(0);
     const int tpp = a.N / 128;                                // tiles per wave and product
     const int G = a.nprod * tpp * a.nseg * CH;                // chunks of eight k-steps this wave walks through
@@ -676,6 +681,15 @@ __global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) {
     }
     ASTAMP(13);
 }
+template <int K>
+__global__ __launch_bounds__(256) void gemm_aw_kernel(AwArgs a) { gemm_aw_block<K>(a, blockIdx.x); }
+// A batch of weight-gradient products and one activation x weight product that do not depend on each other, in one
+// launch (a launch costs several microseconds whatever it does): the first aw_first workgroups take the batch.
+template <int K>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmBatch batch, AwArgs a, int aw_first) {
+    if ((int)blockIdx.x < aw_first) gemm_batch_block(batch, blockIdx.x);
+    else gemm_aw_block<K>(a, blockIdx.x - aw_first);
+}
 static size_t aw_lds_bytes(int K, int nseg) { return (size_t)nseg * 2 * 32 * (K + 8) * 2; }
 static void launch_aw(hipStream_t s, AwArgs a, int K) {
     const int blocks = (a.M + 31) / 32;
@@ -687,6 +701,23 @@ static void launch_aw(hipStream_t s, AwArgs a, int K) {
     } else {
         (void)hipFuncSetAttribute((const void *)gemm_aw_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
         hipLaunchKernelGGL(gemm_aw_kernel<512>, dim3(blocks), dim3(256), aw_lds_bytes(512, 1), s, a);
+    }
+}
+
+static void launch_pair(hipStream_t s, GemmLaunch &gl, AwArgs a, int K) {
+    gl.b.first[gl.b.count] = gl.blocks;
+    const int aw_blocks = (a.M + 31) / 32;
+    const size_t lds = aw_lds_bytes(K, a.nseg) > (size_t)GEMM_LDS_BYTES ? aw_lds_bytes(K, a.nseg) : (size_t)GEMM_LDS_BYTES;
+#ifdef GEMM_STAMPS
+    for (int i = 0; i < gl.b.count; ++i) gl.b.g[i].launch_seq = gemm_launch_seq;
+    a.launch_seq = gemm_launch_seq++;
+#endif
+    if (K == 128) {
+        (void)hipFuncSetAttribute((const void *)gemm_pair_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(128, 3));
+        hipLaunchKernelGGL(gemm_pair_kernel<128>, dim3(gl.blocks + aw_blocks), dim3(256), lds, s, gl.b, a, gl.blocks);
+    } else {
+        (void)hipFuncSetAttribute((const void *)gemm_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
+        hipLaunchKernelGGL(gemm_pair_kernel<512>, dim3(gl.blocks + aw_blocks), dim3(256), lds, s, gl.b, a, gl.blocks);
     }
 }
 
@@ -956,8 +987,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
 //   dQ_i = sum_j dS[i][j] K_j;  dK_j = sum_i dS[i][j] Q_i;  dV_j = sum_i P[i][j] dO_i
 // dS is scaled for the binary16 operands by a bound of its magnitude, |dS[i][j]| <= (|dO_i|_1 max|V| + |dO_i . O_i|) / 4.
 //
-// attn_bwd_q_kernel: a wave owns 32 queries and walks over the key tiles (score tiles transposed, as in the forward).
-__global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+// attn_bwd_q: a wave owns 32 queries and walks over the key tiles (score tiles transposed, as in the forward).
+__device__ __forceinline__ void attn_bwd_q(const float *__restrict__ Q, const float *__restrict__ K,
                                                          const float *__restrict__ V, const float *__restrict__ O,
                                                          const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
                                                          const float *__restrict__ amax_do, const float *__restrict__ stats,
@@ -1022,9 +1053,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float *__restrict
     if (lane == 0) atomic_max_abs(amax_dq, m);
 }
 
-// attn_bwd_kv_kernel: a wave owns 32 keys and walks over the query tiles (score tiles with queries along the rows:
+// attn_bwd_kv: a wave owns 32 keys and walks over the query tiles (score tiles with queries along the rows:
 // the per-query statistics come from LDS, four consecutive queries per accumulator register group).
-__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+__device__ __forceinline__ void attn_bwd_kv(const float *__restrict__ Q, const float *__restrict__ K,
                                                           const float *__restrict__ V, const float *__restrict__ O,
                                                           const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
                                                           const float *__restrict__ amax_do, const float *__restrict__ stats,
@@ -1113,15 +1144,26 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float *__restric
         atomic_max_abs(amax_dkv + AMAX_STRIDE, mv);
     }
 }
+// both halves of the attention backward in one launch: blockIdx.z = 0 computes dQ, 1 computes dK and dV
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+                                                       const float *__restrict__ V, const float *__restrict__ O,
+                                                       const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
+                                                       const float *__restrict__ amax_do, const float *__restrict__ stats,
+                                                       float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV,
+                                                       float *__restrict__ amax_dqkv) {       // bounds of |dQ|, |dK|, |dV|
+    if (blockIdx.z == 0) attn_bwd_q(Q, K, V, O, dO, n, amax_qkv, amax_do, stats, dQ, amax_dqkv);
+    else attn_bwd_kv(Q, K, V, O, dO, n, amax_qkv, amax_do, stats, dK, dV, amax_dqkv + AMAX_STRIDE);
+}
 static size_t attn_lds_bytes(int NT, int rm_images, int t_images, int stat_floats) {
     return (size_t)2 * 2 * (rm_images * 32 * NT * 16 + t_images * 16 * ATT_TS(NT)) + (size_t)stat_floats * 4;
 }
 
 // ------------------------------------------------------------------------------ anchors
-// Decoder entry (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-449): Y = X with the anchor token(s)
-// of every row replaced by  W_a x_anchor + b_a.  One workgroup per (row, anchor), 128 threads.
-__global__ __launch_bounds__(128) void anchor_fwd_kernel(const float *__restrict__ X, float *__restrict__ Y, int n, int tok0_,
-                                                         int tok1_, const float *__restrict__ W0, const float *__restrict__ b0,
+// Decoder entry (TSP/TSPModel.py:304, CVRP/CVRPModel.py:445-449): the anchor token(s) of every row are
+// replaced by  W_a x_anchor + b_a  in place; the replaced rows are kept in Ea[anchor][row][128].
+// One workgroup per (row, anchor), 128 threads.
+__global__ __launch_bounds__(128) void anchor_fwd_kernel(float *__restrict__ X, float *__restrict__ Ea, int n, int tok0_, int tok1_,
+                                                         const float *__restrict__ W0, const float *__restrict__ b0,
                                                          const float *__restrict__ W1, const float *__restrict__ b1,
                                                          float *__restrict__ amax_y) {
     __shared__ float xs[D_MODEL];
@@ -1129,11 +1171,12 @@ __global__ __launch_bounds__(128) void anchor_fwd_kernel(const float *__restrict
     const long tk = (long)r * n + (a == 0 ? tok0_ : tok1_);
     const float *W = a == 0 ? W0 : W1, *b = a == 0 ? b0 : b1;
     xs[c] = X[tk * D_MODEL + c];
+    Ea[((long)a * gridDim.x + r) * D_MODEL + c] = xs[c];          // the encoder's output at the anchor, for the backward pass
     __syncthreads();
     float s = 0.0f;
     for (int k = 0; k < D_MODEL; ++k) s = fmaf(W[c * D_MODEL + k], xs[k], s);
     s += b[c];
-    Y[tk * D_MODEL + c] = s;
+    X[tk * D_MODEL + c] = s;                                       // in place: the row was read into LDS first
     s = wave_max_f32(fabsf(s));
     if ((c & 63) == 0) atomic_max_abs(amax_y, s);
 }
@@ -1367,9 +1410,9 @@ extern "C" int dgl_adam_step(float *params, const float *grads, float *exp_avg, 
 
 // ----------------------------------------------------------------------- orchestration
 // Workspace (floats), M = R*n tokens:
-//   magnitude bounds [64][16 parts, 128 bytes apart] | T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | E [M][128] (encoder
-//   output before the anchor re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row
-//   statistics [R][8][n][2] | backward scratch: dA dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
+//   magnitude bounds [64][16 parts, 128 bytes apart] | T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | Ea [2][R][128] (encoder
+//   output at the anchors, before their re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row
+//   statistics [R][8][n][2] | backward scratch: dA dA2 dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
 //   block's weight and bias gradients | packed weights
 #define AMAX_SLOTS 64
 #define AMAX_FLOATS (AMAX_SLOTS * AMAX_STRIDE)
@@ -1400,8 +1443,8 @@ static size_t part_floats(int R, int n) {
 static size_t ws_floats(int R, int n) {
     const size_t M = (size_t)R * n;
     const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * 2;
-    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 6 * M * D_MODEL + 4 * per_block + 5 * M * D_MODEL + M * FF_DIM + part_floats(R, n) +
-           PACKED_FLOATS;
+    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 5 * M * D_MODEL + 2 * (size_t)R * D_MODEL + 4 * per_block + 6 * M * D_MODEL + M * FF_DIM +
+           part_floats(R, n) + PACKED_FLOATS;
 }
 extern "C" int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n) { return (int64_t)ws_floats(R, n); }
 
@@ -1457,13 +1500,14 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     float *X[5];
     float *p = T + (size_t)M * DGL_TILE_STRIDE;
     for (int l = 0; l < 5; ++l) { X[l] = p; p += MD; }
-    float *E = p; p += MD;
+    float *Ea = p; p += (size_t)2 * R * D_MODEL;
     float *Qb[4], *Kb[4], *Vb[4], *AO[4], *O1[4], *H[4], *P[4];
     for (int l = 0; l < 4; ++l) {
         Qb[l] = p; p += MD; Kb[l] = p; p += MD; Vb[l] = p; p += MD; AO[l] = p; p += MD; O1[l] = p; p += MD;
         H[l] = p; p += MF; P[l] = p; p += PP;
     }
     float *dA = p; p += MD;
+    float *dA2 = p; p += MD;
     float *dB = p; p += MD;
     float *dQ = p; p += MD;
     float *dK = p; p += MD;
@@ -1496,7 +1540,8 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
                 }
             }
         pb.first[pb.count] = blocks;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pb);
+        static_assert(AMAX_FLOATS <= 4 * 96 * 256, "the packing launch has fewer threads than there are bounds to clear");
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pb, ax, (int)AMAX_FLOATS);
     }
     // one product of the activation x weight kernel
     auto aw_product = [](const _Float16 *Bp, float *C, float *amax_c, int ldc) {
@@ -1515,10 +1560,9 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     const int NT = (n + 31) / 32;                      // attention: 32-token tiles, one wave each
     const size_t attn_fwd_lds = attn_lds_bytes(NT, 1, 1, 0), attn_q_lds = attn_lds_bytes(NT, 2, 1, 0),
                  attn_kv_lds = attn_lds_bytes(NT, 2, 2, 3 * 32 * NT + 4);
-    (void)hipFuncSetAttribute((const void *)attn_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
+    (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
 
     // ---- forward
-    (void)hipMemsetAsync(ax, 0, AMAX_FLOATS * sizeof(float), s);
     hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
                        io->tile_row_stride, R, n, T);
     GemmLaunch()
@@ -1528,9 +1572,8 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         const dgl_block_weights_t &k = w->block[l];
         const float *Xin = X[l], *ax_in = bound(AX_X + l);
         if (l == 1) {
-            // E keeps the encoder output; X[1] = E with re-embedded anchors
-            (void)hipMemcpyAsync(E, X[1], MD * sizeof(float), hipMemcpyDeviceToDevice, s);
-            hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, E, X[1], n, anchor0, anchor1,
+            // X[1] = the encoder output with re-embedded anchors; Ea keeps the anchors' encoder output
+            hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, X[1], Ea, n, anchor0, anchor1,
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0], bound(AX_X + 1));
         }
         {   // Q, K, V: three products with the same A
@@ -1581,8 +1624,11 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         const float *Xin = X[l];
         const float *ax_out = bound(AX_DX + l + 1), *ax_h = bound(AX_DH + l), *ax_q = bound(AX_DQKV + 3 * l);
         float *ax_mid = bound(AX_DMID + l);
-        // The dX products run on the packed transposed weights; the weight-gradient products (which also sum their dY
-        // operand over the tokens: the bias gradient) are batched into launches between them.
+        // The dX products run on the packed transposed weights.  The weight-gradient products (which also sum their dY
+        // operand over the tokens: the bias gradient) depend on nothing the chain writes after them, so each batch of
+        // them shares a launch with the chain's next product.  dA holds the gradient of the block's output, dA2 that
+        // of O1 (the batch reading dA runs beside the product writing dA2), and the block's input gradient goes back
+        // into dA.
         // X[l+1] = O1 + W2 H + b2;  H = relu(..): dH = (dA W2) where H > 0
         {
             AwArgs a = aw_args(dA, ax_out, D_MODEL, FF_DIM);
@@ -1590,55 +1636,51 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0].gate = H[l];
             launch_aw(s, a, D_MODEL);
         }
-        float *b2_part = ps.take((float *)g.b2, zm, D_MODEL), *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
-        GemmLaunch()
-            .add(linear_bwd_w(dA, ax_out, D_MODEL, H[l], bound(AX_H + l), FF_DIM, ps.take((float *)g.w2, zm, D_MODEL * FF_DIM), b2_part, M,
-                              D_MODEL, FF_DIM))
-            .add(linear_bwd_w(dH, ax_h, FF_DIM, O1[l], bound(AX_O1 + l), D_MODEL, ps.take((float *)g.w1, zm, FF_DIM * D_MODEL), b1_part, M,
-                              FF_DIM, D_MODEL))
-            .run(s);
-        {   // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1   (accumulated into dA)
+        {   // H = relu(W1 O1 + b1);  dO1 = dA + dHpre W1, beside dW2 and dW1
+            float *b2_part = ps.take((float *)g.b2, zm, D_MODEL), *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
+            GemmLaunch gl;
+            gl.add(linear_bwd_w(dA, ax_out, D_MODEL, H[l], bound(AX_H + l), FF_DIM, ps.take((float *)g.w2, zm, D_MODEL * FF_DIM), b2_part, M,
+                                D_MODEL, FF_DIM))
+                .add(linear_bwd_w(dH, ax_h, FF_DIM, O1[l], bound(AX_O1 + l), D_MODEL, ps.take((float *)g.w1, zm, FF_DIM * D_MODEL), b1_part, M,
+                                  FF_DIM, D_MODEL));
             AwArgs a = aw_args(dH, ax_h, FF_DIM, D_MODEL);
-            a.p[0] = aw_product(pk[1][l][4], dA, ax_mid, D_MODEL);
-            a.p[0].mode = 1;
-            launch_aw(s, a, FF_DIM);
+            a.p[0] = aw_product(pk[1][l][4], dA2, ax_mid, D_MODEL);
+            a.p[0].add = dA; a.p[0].ldadd = D_MODEL;
+            launch_pair(s, gl, a, FF_DIM);
         }
-        {   // O1 = Xin + Wc AO + bc:  dB = dAO = dA Wc
-            AwArgs a = aw_args(dA, ax_mid, D_MODEL, D_MODEL);
+        {   // O1 = Xin + Wc AO + bc:  dB = dAO = dO1 Wc
+            AwArgs a = aw_args(dA2, ax_mid, D_MODEL, D_MODEL);
             a.p[0] = aw_product(pk[1][l][3], dB, bound(AX_DB + l), D_MODEL);
             launch_aw(s, a, D_MODEL);
         }
-        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(R, HEADS), dim3(64 * NT), attn_q_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
-                           bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dQ, bound(AX_DQKV + 3 * l));
-        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(R, HEADS), dim3(64 * NT), attn_kv_lds, s, Qb[l], Kb[l], Vb[l], AO[l], dB, n,
-                           bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dK, dV, bound(AX_DQKV + 3 * l + 1));
-        float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
-        GemmLaunch()
-            .add(linear_bwd_w(dA, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
-                              D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dQ, ax_q, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wq, zm, D_MODEL * D_MODEL), nullptr, M,
-                              D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL),
-                              nullptr, M, D_MODEL, D_MODEL))
-            .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL),
-                              nullptr, M, D_MODEL, D_MODEL))
-            .run(s);
-        {   // dXin = dA + dQ Wq + dK Wk + dV Wv: the three products accumulate in one tile, added to dA in place
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS, 2), dim3(64 * NT), attn_kv_lds > attn_q_lds ? attn_kv_lds : attn_q_lds, s, Qb[l],
+                           Kb[l], Vb[l], AO[l], dB, n, bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dQ, dK, dV, bound(AX_DQKV + 3 * l));
+        {   // dXin = dO1 + dQ Wq + dK Wk + dV Wv (the three products accumulate in one tile), beside dWc, dWq, dWk, dWv
+            float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
+            GemmLaunch gl;
+            gl.add(linear_bwd_w(dA2, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
+                                D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dQ, ax_q, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wq, zm, D_MODEL * D_MODEL), nullptr, M,
+                                  D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL),
+                                  nullptr, M, D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL),
+                                  nullptr, M, D_MODEL, D_MODEL));
             AwArgs a = aw_args(dQ, ax_q, D_MODEL, D_MODEL);
             a.A[1] = dK; a.amax_a[1] = ax_q + AMAX_STRIDE;
             a.A[2] = dV; a.amax_a[2] = ax_q + 2 * AMAX_STRIDE;
             a.nseg = 3;
             a.p[0] = aw_product(pk[1][l][0], dA, bound(AX_DX + l), D_MODEL);
             a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
-            a.p[0].add = dA; a.p[0].ldadd = D_MODEL;
-            launch_aw(s, a, D_MODEL);
+            a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
+            launch_pair(s, gl, a, D_MODEL);
         }
         if (l == 1) {
             // dW_a[c][k] += sum_r dA[anchor of row r][c] E[anchor of row r][k]: the rows' anchor tokens are n tokens apart
             GemmLaunch gl;
             for (int a = 0; a < n_anchor; ++a) {
                 const long off = (long)(a == 0 ? anchor0 : anchor1) * D_MODEL;
-                gl.add(linear_bwd_w(dA + off, bound(AX_DX + 1), (long)n * D_MODEL, E + off, bound(AX_X + 1), (long)n * D_MODEL,
+                gl.add(linear_bwd_w(dA + off, bound(AX_DX + 1), (long)n * D_MODEL, Ea + (size_t)a * R * D_MODEL, bound(AX_X + 1), D_MODEL,
                                     ps.take((float *)grad->anchor_w[a], zr, D_MODEL * D_MODEL), nullptr, R, D_MODEL, D_MODEL));
             }
             gl.run(s);

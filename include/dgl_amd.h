@@ -276,24 +276,28 @@ DGL_API int dgl_tsp_greedy_decode(const dgl_tsp_state_t *st, const float *packed
 
 /* ------------------------------------------------------- general forward / training step
  * The same network for ANY number of tokens per row (2 <= n <= 256; e.g. knn = depot_knn = 100,
- * CVRP/train.py:130-131), evaluated as a sequence of plain f32 matrix kernels over the flattened
- * token axis, and its backward pass: the model side of CVRPTrainer._train_one_batch
+ * CVRP/train.py:130-131), evaluated as a sequence of matrix and attention kernels over the flattened
+ * token axis (binary32 tensors; products on the f16 matrix cores with operands split into two
+ * binary16 halves, 22 significant bits, binary32 accumulation), and its backward pass: the model
+ * side of CVRPTrainer._train_one_batch
  * (CVRP/CVRPTrainer.py:268-271: model(...) in mode 'train' -> probability of the teacher's
  * action, CVRP/CVRPModel.py:311-345 / TSP/TSPModel.py:206-217; loss = -log(prob).mean();
  * loss.backward()).
  *  w     : raw weights (device pointers, reference state_dict layout), as for dgl_policy_pack.
  *  grad  : NULL = inference only.  Otherwise the same struct over gradient buffers (one per
- *          tensor, same shapes, pointers cast to const float*): gradients are ADDED to them
- *          (float atomics), so zero them first (model.zero_grad()).
+ *          tensor, same shapes, pointers cast to const float*): gradients are ADDED to them,
+ *          so zero them first (model.zero_grad()).  Sums over tokens are ordered sums of partial
+ *          sums: the same call on the same data gives the same bits.
  *  teacher [R] (may be NULL when grad is NULL): the teacher's action per row (TSP node id; CVRP
  *          node id, + N+1 when the move goes via the depot).  teacher_prob_out [R] (may be NULL)
  *          receives the floored probability of that action, 1e-20 when it is not a candidate
  *          token (the dense tensor the reference indexes holds 1e-20 there).
  *  grad_scale: d(loss)/d(-log p_r), i.e. 1 / (rows of the global batch) for the reference's mean.
- *  ws    : dgl_policy_general_workspace_floats(R, n) floats of scratch (activations are kept
- *          there between the forward and the backward half of the call).
+ *  ws    : dgl_policy_general_workspace_floats(R, n) floats of scratch, 16-byte aligned
+ *          (activations are kept there between the forward and the backward half of the call,
+ *          with the weights repacked for the matrix cores and the partial sums of the gradients).
  *  io    : as for dgl_policy_forward (logits_out / prob_out / selected_out are written when
- *          given, with io->out_stride floats per row); io->arithmetic is ignored (binary32). */
+ *          given, with io->out_stride floats per row); io->arithmetic is ignored. */
 DGL_API int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n);
 DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
                                const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,
@@ -303,8 +307,8 @@ DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_w
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
  * reference.  The workspace is a device array inside the library of DGL_STATIC_WORKSPACE_FLOATS floats (64 MiB,
  * held on every device the library runs on until the process ends), so
- * dgl_policy_general_workspace_floats(io->R, io->n) must not exceed that (about 2500 tokens: 12 rows of 202
- * tokens, 79 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
+ * dgl_policy_general_workspace_floats(io->R, io->n) must not exceed that (about 2000 tokens: 10 rows of 202
+ * tokens, 66 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
  * No hipMalloc / hipFree or other allocating call is made.  The first call on a device looks the array's
  * address up (make it outside graph capture).  All calls on one device share the array: calls that overlap in
  * time on one device race.  Arguments and results otherwise exactly as dgl_policy_general. */
