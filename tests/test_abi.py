@@ -59,3 +59,27 @@ def test_instances_of_at_most_25_points_are_refused():
     assert lib.dgl_cvrp_reset(ctypes.byref(cv), None) == -2
     assert lib.dgl_tsp_nearest_neighbour(fake, 2, 25, fake, fake, None) == -2
     assert lib.dgl_cvrp_nearest_neighbour(fake, fake, 2, 24, fake, fake, None) == -2
+
+
+def test_general_path_refuses_bad_token_counts_and_misaligned_workspace():
+    """dgl_policy_general checks its arguments before anything is launched: 2 <= n <= 256 tokens per row, the TSP token
+    layout, and a 16-byte aligned workspace (its kernels read it 16 bytes at a time)."""
+    import ctypes
+    from dgl_amd import _lib
+    lib = _lib.load()
+    fake = 4096                                   # never dereferenced: the checks come first
+    w = _lib.PolicyWeights()
+    w.problem = _lib.PROBLEM_TSP
+    io = _lib.PolicyIO()
+    io.problem, io.R, io.n, io.k_last, io.N = _lib.PROBLEM_TSP, 4, 51, 50, 100
+    io.idx_stride, io.tile_row_stride, io.out_stride = 50, 51 * _lib.TILE_STRIDE, 64
+    io.tile, io.idx_last = fake, fake
+    args = (ctypes.byref(w), None, ctypes.byref(io), None, ctypes.c_float(0.0))
+    assert lib.dgl_policy_general(*args, fake + 4, None, None) == -1              # DGL_ERR_INVALID_ARGUMENT
+    assert b"aligned" in lib.dgl_last_error_string()
+    io.n, io.k_last = 257, 256
+    assert lib.dgl_policy_general(*args, fake, None, None) == -1
+    assert b"n=257" in lib.dgl_last_error_string()
+    io.n, io.k_last = 51, 40                                                      # TSP: the anchor is the last token
+    assert lib.dgl_policy_general(*args, fake, None, None) == -1
+    assert lib.dgl_policy_general_workspace_floats(64, 202) > lib.dgl_policy_general_workspace_floats(10, 202) > 0

@@ -83,7 +83,7 @@ def test_tsp_train_step_matches_autograd(N, knn, device):
     print(f"TSP N={N} n={knn + 1}: loss {loss_ref:.6f}, worst relative gradient error {worst:.2e}")
 
 
-@pytest.mark.parametrize("N,knn,kd", [(80, 15, 15), (120, 25, 25), (260, 100, 100)])
+@pytest.mark.parametrize("N,knn,kd", [(80, 15, 15), (120, 25, 25), (260, 100, 100), (300, 127, 127)])      # 32, 52, 202, 256 tokens (the maximum)
 def test_cvrp_train_step_matches_autograd(N, knn, kd, device):
     from dgl_amd._lib import PROBLEM_CVRP
     from dgl_amd.train import PolicyTrainer
