@@ -419,85 +419,99 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         STAMP2();
 
         // ---- feed forward: 4 hidden chunks of 128, hidden images alternate between B and C ----
-        // Software pipeline: the epilogue of chunk hc (bias, ReLU, split, LDS stores: VALU work) is
-        // interleaved with the MFMAs of the second GEMM of chunk hc-1, which do not depend on it:
-        //   G1(0) E(0) | G1(1) [E(1) || G2(0)] | G1(2) [E(2) || G2(1)] | G1(3) [E(3) || G2(2)] | G2(3)
-        // (| = workgroup barrier).  The weight stream is packed in this order.
+        // Software pipeline: the epilogue E(hc) of a chunk's first GEMM (bias, ReLU, split, LDS stores: VALU work)
+        // is written between the MFMAs of GEMMs that do not depend on it - the second GEMM of the chunk before and
+        // the first GEMM of the chunk after, half of it in each:
+        //   G1(0) [G1(1) || E(0)] | [G2(0) || E(1)a] [G1(2) || E(1)b] | [G2(1) || E(2)a] [G1(3) || E(2)b] |
+        //   [G2(2) || E(3)] | G2(3)                                   (| = workgroup barrier)
+        // The weight stream is packed in this order: W1.0 W1.1 W2.0 W1.2 W2.1 W1.3 W2.2 W2.3.
         {
-            f32x16 af[ROWS];
+            f32x16 af[ROWS], ahA[ROWS], ahB[ROWS];
 #pragma unroll
-            for (int rr = 0; rr < ROWS; ++rr) af[rr] = zero16();
-            auto hidden_epilogue = [&](auto hcc, f32x16 (&ah)[ROWS]) {
-                constexpr int hc = decltype(hcc)::value;
-                _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
+            for (int rr = 0; rr < ROWS; ++rr) { af[rr] = zero16(); ahA[rr] = zero16(); ahB[rr] = zero16(); }
+            // registers of an epilogue in flight
+            float v0[ROWS], v1[ROWS], t0[ROWS], t1[ROWS];
+            unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS];
+            f32x4 bb[4];
+            auto load_bias = [&](int hc) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = vec4(PV + PKV_B1 + 128 * hc, g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int rr = 0; rr < ROWS; ++rr) ah[rr][4 * g + e] = fmaxf(ah[rr][4 * g + e] + bb[e], 0.0f);
-                }
-#pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) store_split(ah[rr], HH + rr * ROWH + wr, HL + rr * ROWH + wr, range_mx);
+                for (int g = 0; g < 4; ++g) bb[g] = vec4(PV + PKV_B1 + 128 * hc, g);
             };
-            Unroll<0, 4>::run([&](auto hcc) {
-                constexpr int hc = decltype(hcc)::value;
-                f32x16 ah[ROWS];
-#pragma unroll
-                for (int rr = 0; rr < ROWS; ++rr) ah[rr] = zero16();
-                gemm16_t<ROWS, ROWH, (hc == 0 ? 64 : 48 + 32 * hc)>(ring, XH + rd, XL + rd, ah);
-                STAMP2();  // G1(hc) done
-                if constexpr (hc == 0) {
-                    hidden_epilogue(hcc, ah);
+            // piece (st, rr, part) of the epilogue of one chunk: step st = 0..7 handles registers 2 st, 2 st + 1 of
+            // row rr in three parts (bias + ReLU | hi | lo and, every second step, the 8-byte stores)
+            auto piece = [&](auto stc, auto rc, auto pp, const f32x16 (&ah)[ROWS], _Float16 *HH, _Float16 *HL) {
+                constexpr int st = decltype(stc)::value, rr = decltype(rc)::value, part = decltype(pp)::value;
+                constexpr int g = st / 2, e = 2 * (st & 1);
+                if constexpr (part == 0) {
+                    v0[rr] = fmaxf(ah[rr][2 * st] + bb[g][e], 0.0f);
+                    v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
+                } else if constexpr (part == 1) {
+                    hq[rr] = pack_rtz(v0[rr], v1[rr]);
+                    track_range(v0[rr], v1[rr], range_mx);
+                    t0[rr] = minus_half_lo(v0[rr], hq[rr]);
+                    t1[rr] = minus_half_hi(v1[rr], hq[rr]);
                 } else {
-                    constexpr int pc = hc - 1;                       // chunk whose second GEMM runs now
-                    _Float16 *PH = (pc & 1) ? CH : BH, *PL = (pc & 1) ? CL : BL;
-                    _Float16 *HH = (hc & 1) ? CH : BH, *HL = (hc & 1) ? CL : BL;
-                    f32x4 bb[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) bb[g] = vec4(PV + PKV_B1 + 128 * hc, g);
-                    // epilogue of chunk hc in 8 x ROWS x 3 pieces: K-step s handles registers 2s, 2s+1 of each
-                    // row (bias + ReLU | hi | lo and, every second step, the 8-byte stores)
-                    float v0[ROWS], v1[ROWS], t0[ROWS], t1[ROWS];
-                    unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS];
-                    auto side = [&](auto ss, auto rc, auto pp) {
-                        constexpr int st = decltype(ss)::value, rr = decltype(rc)::value, part = decltype(pp)::value;
-                        constexpr int g = st / 2, e = 2 * (st & 1);
-                        if constexpr (part == 0) {
-                            v0[rr] = fmaxf(ah[rr][2 * st] + bb[g][e], 0.0f);
-                            v1[rr] = fmaxf(ah[rr][2 * st + 1] + bb[g][e + 1], 0.0f);
-                        } else if constexpr (part == 1) {
-                            hq[rr] = pack_rtz(v0[rr], v1[rr]);
-                            track_range(v0[rr], v1[rr], range_mx);
-                            t0[rr] = minus_half_lo(v0[rr], hq[rr]);
-                            t1[rr] = minus_half_hi(v1[rr], hq[rr]);
-                        } else {
-                            lq[rr] = pack_rtz(t0[rr], t1[rr]);
-                            if constexpr (st & 1) {
-                                *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
-                                *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
-                            } else {
-                                hp[rr] = hq[rr];
-                                lp[rr] = lq[rr];
-                            }
-                        }
-                    };
-                    gemm16_t_with<ROWS, ROWH, 64 + 32 * hc>(ring, PH + rd, PL + rd, af, side);
+                    lq[rr] = pack_rtz(t0[rr], t1[rr]);
+                    if constexpr (st & 1) {
+                        *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
+                        *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
+                    } else {
+                        hp[rr] = hq[rr];
+                        lp[rr] = lq[rr];
+                    }
                 }
-                STAMP2();  // epilogue / G2(hc-1) done
-                __syncthreads();
-                STAMP2();  // barrier
-                if constexpr (hc == 3) gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);
-                if constexpr (hc == 3) STAMP2();  // G2(3) done
-            });
+            };
+            // a whole epilogue inside one GEMM (one step per K-step), or half of one (a step on every second K-step)
+            auto whole = [&](const f32x16 (&ah)[ROWS], _Float16 *HH, _Float16 *HL) {
+                return [&, HH, HL](auto ss, auto rc, auto pp) { piece(ss, rc, pp, ah, HH, HL); };
+            };
+            auto half = [&](auto first, const f32x16 (&ah)[ROWS], _Float16 *HH, _Float16 *HL) {
+                return [&, HH, HL](auto ss, auto rc, auto pp) {
+                    constexpr int s = decltype(ss)::value, st0 = decltype(first)::value;
+                    if constexpr ((s & 1) == 0) piece(std::integral_constant<int, st0 + s / 2>{}, rc, pp, ah, HH, HL);
+                };
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I4 = std::integral_constant<int, 4>;
+            gemm16_t<ROWS, ROWH, 64>(ring, XH + rd, XL + rd, ahA);                                     // G1(0)
+            STAMP2();
+            load_bias(0);
+            gemm16_t_with<ROWS, ROWH, 80>(ring, XH + rd, XL + rd, ahB, whole(ahA, BH, BL));            // G1(1) || E(0)
+            STAMP2();
+            __syncthreads();
+            STAMP2();
+            load_bias(1);
+            gemm16_t_with<ROWS, ROWH, 96>(ring, BH + rd, BL + rd, af, half(I0{}, ahB, CH, CL));        // G2(0) || E(1)a
+            STAMP2();
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) ahA[rr] = zero16();
+            gemm16_t_with<ROWS, ROWH, 112>(ring, XH + rd, XL + rd, ahA, half(I4{}, ahB, CH, CL));       // G1(2) || E(1)b
+            STAMP2();
+            __syncthreads();
+            STAMP2();
+            load_bias(2);
+            gemm16_t_with<ROWS, ROWH, 128>(ring, CH + rd, CL + rd, af, half(I0{}, ahA, BH, BL));        // G2(1) || E(2)a
+            STAMP2();
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) ahB[rr] = zero16();
+            gemm16_t_with<ROWS, ROWH, 144>(ring, XH + rd, XL + rd, ahB, half(I4{}, ahA, BH, BL));       // G1(3) || E(2)b
+            STAMP2();
+            __syncthreads();
+            STAMP2();
+            load_bias(3);
+            gemm16_t_with<ROWS, ROWH, 160>(ring, BH + rd, BL + rd, af, whole(ahB, CH, CL));             // G2(2) || E(3)
+            STAMP2();
+            __syncthreads();
+            STAMP2();
+            gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);                                      // G2(3)
+            STAMP2();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bb = vec4(PV + PKV_B2, g);
+                const f32x4 b2 = vec4(PV + PKV_B2, g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (af[rr][4 * g + e] + bb[e]);
+                    for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (af[rr][4 * g + e] + b2[e]);
             }
             // the last barrier came after every wave's last read of X (W1 of chunk 3)
             if (layer < 3) {

@@ -12,9 +12,8 @@ eng.reset(); eng.step(torch.zeros(R, dtype=torch.int32, device=dev))
 for _ in range(3): eng.forward(pol)
 torch.cuda.synchronize()
 st = eng.logits.view(R, 32)[0::2].cpu()
-names = ["qkv", "attn", "bar", "comb", "bar"]
-for hc in range(4): names += [f"G1({hc})", f"E({hc})|G2({hc - 1})" if hc else "E(0)", "bar"]
-names += ["G2(3)", "resid+store", "bar"]
+names = ["qkv", "attn", "bar", "comb", "bar", "G1(0)", "G1(1)|E(0)", "bar", "G2(0)|E(1)a", "G1(2)|E(1)b", "bar",
+         "G2(1)|E(2)a", "G1(3)|E(2)b", "bar", "G2(2)|E(3)", "bar", "G2(3)", "resid+store", "bar"]
 d = (st[:, 1:] - st[:, :-1]).median(0).values
 for i, nm in enumerate(names):
     print(f"{nm:14s} {d[i].item():8.0f}")
