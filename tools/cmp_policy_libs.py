@@ -29,7 +29,7 @@ for R in (512, 37):
         ce.forward(cpol, want_logits=True, want_prob=True)
         out += [ce.logits.cpu().numpy().tobytes(), ce.prob.cpu().numpy().tobytes(), ce.selected.cpu().numpy().tobytes()]
         ce.step(ce.selected)
-print(hashlib.sha256(b''.join(out)).hexdigest())
+print(hashlib.sha256(b''.join(out)).hexdigest(), ' '.join(hashlib.sha256(o).hexdigest()[:6] for o in out) if os.environ.get('CMP_VERBOSE') else '')
 ''' % HERE
 digests = {}
 for lib in sys.argv[1].split(","):
