@@ -15,7 +15,7 @@
 #define BEAM_THREADS 256
 #define BEAM_MAX 256
 #define DENSE_CAP 2048      // candidate keys kept in LDS by the dense kernel
-#define COMPACT_CAP 8192    // beam * tokens upper bound for the compact kernel
+#define COMPACT_CAP 8192    // explicit candidates the compact kernel sorts in LDS (more: two passes and a gather)
 
 typedef unsigned long long u64;
 #define BEAM_FAST 32        // beams up to this size are extracted by repeated wave-wide maxima instead of a sort
@@ -155,41 +155,103 @@ __device__ __forceinline__ int token_action(const dgl_policy_io_t &io, int r, in
     return io.idx_depot[(size_t)r * io.idx_dep_stride + (tok - io.k_last - 1)] + io.N + 1;
 }
 
+// key of explicit candidate e = (beam b, token) of group g, 0 for an anchor token
+__device__ __forceinline__ u64 compact_key(const dgl_policy_io_t &io, const float *__restrict__ prob, const float *sc, int g,
+                                           int beam, int A, int step, int e) {
+    const int n = io.n;
+    const int b = e / n, tok = e % n, r = g * beam + b;
+    // (requested before the action is known: two independent loads instead of two round trips)
+    const float pv = prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok];
+    const int act = token_action(io, r, tok);
+    if (act < 0) return 0;
+    const float lpv = logf(pv);
+    const float v = step >= 2 ? __fadd_rn(lpv, sc[b]) : (b == 0 ? lpv : -1e20f);
+    return make_key(v, (unsigned)b * (unsigned)A + (unsigned)act);
+}
+
+// P: LDS slots for explicit candidates (a power of two).  beam * n <= P: every explicit candidate is sorted in LDS.
+// beam * n > P (wide beams over rows of many tokens, e.g. beam 100 x 202 tokens, CVRP/train.py:70,130-131): two
+// passes over the candidates as in the dense kernel - the beam-th best of the per-thread maxima bounds the beam-th
+// best key from below, the keys at or above it (a few hundred) are gathered and sorted.
 __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_io_t io, const float *__restrict__ prob,
                                                                    float *scores, int beam, int A, int step,
                                                                    int32_t *prev_k_out, int32_t *action_out, int P) {
     extern __shared__ u64 ckeys[];          // [P] explicit candidates, then [beam] merged result
     __shared__ float sc[BEAM_MAX];
+    __shared__ int counter;
     const int g = blockIdx.x, tid = threadIdx.x;
     const int n = io.n;
     for (int b = tid; b < beam; b += blockDim.x) sc[b] = scores[(size_t)g * beam + b];
+    if (tid == 0) counter = 0;
     __syncthreads();
     const int ncand = beam * n;
-    for (int e = tid; e < P; e += BEAM_THREADS) {
-        u64 k = 0;
-        if (e < ncand) {
-            const int b = e / n, tok = e % n, r = g * beam + b;
-            // (requested before the action is known: two independent loads instead of two round trips)
-            const float pv = prob[(size_t)r * (io.out_stride > 0 ? io.out_stride : DGL_MAX_TOKENS) + tok];
-            const int act = token_action(io, r, tok);
-            if (act >= 0) {
-                const float lpv = logf(pv);
-                const float v = step >= 2 ? __fadd_rn(lpv, sc[b]) : (b == 0 ? lpv : -1e20f);
-                k = make_key(v, (unsigned)b * (unsigned)A + (unsigned)act);
+    int n_explicit = P;                     // sorted explicit keys available below
+    if (ncand <= P) {
+        for (int e = tid; e < P; e += BEAM_THREADS) ckeys[e] = e < ncand ? compact_key(io, prob, sc, g, beam, A, step, e) : 0;
+        __syncthreads();
+    } else {
+        u64 best = 0;
+        for (int e = tid; e < ncand; e += BEAM_THREADS) {
+            const u64 k = compact_key(io, prob, sc, g, beam, A, step, e);
+            best = k > best ? k : best;
+        }
+        ckeys[tid] = best;
+        __syncthreads();
+        block_sort_desc(ckeys, BEAM_THREADS);
+        u64 lb = ckeys[min(beam, BEAM_THREADS) - 1];
+        __syncthreads();
+        for (int e = tid; e < ncand; e += BEAM_THREADS) {
+            const u64 k = compact_key(io, prob, sc, g, beam, A, step, e);
+            if (k >= lb && k != 0) {
+                const int pos = atomicAdd(&counter, 1);
+                if (pos < P) ckeys[pos] = k;
             }
         }
-        ckeys[e] = k;
+        __syncthreads();
+        int c = counter;
+        __syncthreads();
+        if (c > P) {
+            // more keys at or above the bound than slots (many equal values): the beam-th largest key exactly, by
+            // bisection on its bits, then the keys at or above it (exactly `beam` of them: keys are unique)
+            u64 res = 0;
+            for (int bit = 63; bit >= 0; --bit) {
+                const u64 cand = res | (1ull << bit);
+                if (tid == 0) counter = 0;
+                __syncthreads();
+                int local = 0;
+                for (int e = tid; e < ncand; e += BEAM_THREADS) local += compact_key(io, prob, sc, g, beam, A, step, e) >= cand;
+                atomicAdd(&counter, local);
+                __syncthreads();
+                if (counter >= beam) res = cand;
+                __syncthreads();
+            }
+            if (tid == 0) counter = 0;
+            __syncthreads();
+            for (int e = tid; e < ncand; e += BEAM_THREADS) {
+                const u64 k = compact_key(io, prob, sc, g, beam, A, step, e);
+                if (k >= res && k != 0) {
+                    const int pos = atomicAdd(&counter, 1);
+                    if (pos < P) ckeys[pos] = k;
+                }
+            }
+            __syncthreads();
+            c = min(counter, P);
+            __syncthreads();
+        }
+        n_explicit = BEAM_THREADS;
+        while (n_explicit < c) n_explicit <<= 1;
+        for (int i = c + tid; i < n_explicit; i += BEAM_THREADS) ckeys[i] = 0;
+        __syncthreads();
     }
-    __syncthreads();
     // The `beam` largest explicit keys in descending order.  Few beams over at most 512 candidates: one wave holds
     // all keys in registers and extracts the maximum `beam` times (keys are unique); otherwise a block-wide sort.
     __shared__ u64 top[BEAM_FAST];
-    const bool fast = beam <= BEAM_FAST && P <= 512;
+    const bool fast = beam <= BEAM_FAST && n_explicit <= 512;
     if (fast) {
         if (tid < 64) {
             u64 k[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) k[q] = (tid + 64 * q < P) ? ckeys[tid + 64 * q] : 0;
+            for (int q = 0; q < 8; ++q) k[q] = (tid + 64 * q < n_explicit) ? ckeys[tid + 64 * q] : 0;
             // each lane sorts its eight keys once (descending, 19 compare-exchanges); its largest is then k[0], and
             // the lane that owned an extracted maximum shifts its list up
 #define BEAM_CE(i, j) { const u64 a_ = k[i], b_ = k[j]; const bool sw_ = a_ < b_; k[i] = sw_ ? b_ : a_; k[j] = sw_ ? a_ : b_; }
@@ -211,10 +273,10 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_compact_kernel(dgl_policy_i
         }
         __syncthreads();
     } else {
-        block_sort_desc(ckeys, P);
+        block_sort_desc(ckeys, n_explicit);
     }
     const u64 *sorted = fast ? top : ckeys;
-    const int n_sorted = fast ? beam : P;
+    const int n_sorted = fast ? beam : n_explicit;
 
     // implicit candidates: every action of beam b that is not one of its tokens has probability 1e-20
     // (value log(1e-20) + score_b, or -1e20 for b > 0 at step 1).  They only matter when fewer than
@@ -283,8 +345,7 @@ extern "C" int dgl_beam_advance_compact(const dgl_policy_io_t *io, const float *
     DGL_CHECK_ARG(A == need, "A=%d but the action space is %d", A, need);
     DGL_CHECK_ARG(A >= beam, "A=%d < beam=%d", A, beam);
     int P = BEAM_THREADS;
-    while (P < beam * io->n) P <<= 1;
-    DGL_CHECK_ARG(P <= COMPACT_CAP, "beam*n=%d exceeds %d", beam * io->n, COMPACT_CAP);
+    while (P < beam * io->n && P < COMPACT_CAP) P <<= 1;       // more candidates than slots: the kernel's two-pass form
     size_t lds = (size_t)(P + beam) * sizeof(u64);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)beam_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

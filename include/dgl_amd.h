@@ -367,7 +367,9 @@ DGL_API int dgl_beam_advance(const float *log_prob, float *scores, int32_t G, in
 /* The same decision (utils/beamsearch.py:65-99) from the compact per-token probabilities
  * (prob [R][DGL_MAX_TOKENS] as written
  * by dgl_policy_forward, R = G*beam): candidates are the tokens' actions plus the implicit
- * 1e-20 entries of every other action, exactly as the dense form. */
+ * 1e-20 entries of every other action, exactly as the dense form.  beam <= 256; any number of
+ * tokens per row (beam 100 over rows of 202 tokens is the reference's training setting,
+ * CVRP/train.py:70,130-131). */
 DGL_API int dgl_beam_advance_compact(const dgl_policy_io_t *io, const float *prob, float *scores, int32_t G,
                              int32_t beam, int32_t A, int32_t step, int32_t *prev_k_out,
                              int32_t *action_out, dgl_stream_t stream);

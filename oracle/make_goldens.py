@@ -320,6 +320,12 @@ TRAINED_CASES = {
     "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
     "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
     "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),
+    # the reference's default beam width with its training neighbourhoods (CVRP/train.py:70,130-131: beam 100,
+    # knn = depot_knn = 100): 100 x 101 and 100 x 202 explicit candidates per group.  (With fewer candidates than
+    # beams at the first expansion the reference itself fails: the beam then holds visited nodes and the shape
+    # assertion of TSP/TSPModel.py:65 fires.)
+    "tsp_n150_b1_beam100_k100_nn": ("tsp", dict(seed=77, B=1, N=150, knn=100, beam=100, light="tours")),
+    "cvrp_n100_b1_beam100_k100_nn": ("cvrp", dict(seed=77, B=1, N=100, knn=100, depot_knn=100, beam=100, light="tours")),
     # more than 32 tokens per row: the CVRPLIB setting (CVRP/test_cvrplib.py:326-327) and a TSP row of 51 tokens
     "cvrp_n200_b4_k50_nn": ("cvrp", dict(seed=321, B=4, N=200, knn=50, depot_knn=50)),
     "tsp_n200_b4_k50_nn": ("tsp", dict(seed=321, B=4, N=200, knn=50)),

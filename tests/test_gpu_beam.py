@@ -35,10 +35,13 @@ def _setup(name, device):
 
 
 @pytest.mark.parametrize("name", ["tsp_n60_b2_beam4_pomo2", "tsp_n200_b1_beam16", "tsp_n200_b2_beam8_nn",
-                                  "cvrp_n60_b2_beam4_pomo2", "cvrp_n150_b2_beam8_nn"])
+                                  "cvrp_n60_b2_beam4_pomo2", "cvrp_n150_b2_beam8_nn",
+                                  "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn"])
 def test_teacher_forced_beam_steps(name, device):
     """At every step: dense and compact kernels agree with each other and with the reference's
-    (scores, prev_k, action); the state is then advanced with the reference's own choice."""
+    (scores, prev_k, action); the state is then advanced with the reference's own choice.
+    The beam-100 cases are the reference's training setting (CVRP/train.py:70,130-131: beam 100 over rows of 101 / 202
+    tokens): more explicit candidates per group than the compact kernel sorts in LDS."""
     from dgl_amd import _lib
     lib = _lib.load()
     case, eng, pol, beam, A, start = _setup(name, device)
@@ -50,7 +53,7 @@ def test_teacher_forced_beam_steps(name, device):
     ac_d = torch.zeros_like(pk_d)
     pk_c, ac_c = torch.zeros_like(pk_d), torch.zeros_like(pk_d)
     nsteps = case["beam_scores"].shape[0]
-    mism_dense = mism_compact = 0
+    mism_dense = mism_compact = n_sep = 0
     max_score_err = 0.0
     for s in range(nsteps):
         step = s + 1
@@ -62,21 +65,34 @@ def test_teacher_forced_beam_steps(name, device):
                                         ac_d.data_ptr(), _lib.stream_ptr()), "dense")
         eng.beam_advance(sc_c, beam, step, pk_c, ac_c)
         g_sc, g_pk, g_ac = case["beam_scores"][s], case["beam_prev_k"][s], case["beam_action"][s]
-        # reference: exact agreement expected wherever consecutive best scores are separated
-        sep = np.abs(np.diff(g_sc, axis=1)).min(axis=1) > 1e-4 if beam > 1 else np.ones(G, bool)
-        ok_d = (pk_d.cpu().numpy() == g_pk).all(axis=1) & (ac_d.cpu().numpy() == g_ac).all(axis=1)
-        ok_c = (pk_c.cpu().numpy() == g_pk).all(axis=1) & (ac_c.cpu().numpy() == g_ac).all(axis=1)
+        # reference: exact agreement expected at every position whose score is separated from both neighbours'
+        # (separated: by more than the two score lists differ at this step - candidates whose reference scores lie
+        # closer together than the device's scores are off may legitimately change places)
+        eps = float(np.abs(sc_c.cpu().numpy() - g_sc).max(initial=0.0))
+        gap = np.abs(np.diff(g_sc, axis=1)) > max(1e-4, 2.5 * eps) if beam > 1 else np.ones((G, 0), bool)
+        # (the last position competes with a candidate the reference did not keep: its margin is unknown)
+        sep = np.concatenate([np.ones((G, 1), bool), gap], axis=1) & np.concatenate([gap, np.zeros((G, 1), bool)], axis=1)
+        if beam == 1:
+            sep[:] = True
+        ok_d = (pk_d.cpu().numpy() == g_pk) & (ac_d.cpu().numpy() == g_ac)
+        ok_c = (pk_c.cpu().numpy() == g_pk) & (ac_c.cpu().numpy() == g_ac)
         mism_dense += int((~ok_d & sep).sum())
         mism_compact += int((~ok_c & sep).sum())
-        max_score_err = max(max_score_err, float(np.abs(sc_c.cpu().numpy() - g_sc)[ok_c].max(initial=0.0)))
+        n_sep += int(sep.sum())
+        # the two kernels see the same probabilities: they must agree everywhere, ties included
+        assert torch.equal(pk_d, pk_c) and torch.equal(ac_d, ac_c), f"dense and compact expansion differ at step {step}"
+        # the score lists agree as lists whatever the order among near-ties
+        max_score_err = max(max_score_err, float(np.abs(sc_c.cpu().numpy() - g_sc).max(initial=0.0)))
         # continue from the reference's decision
         scores = torch.from_numpy(g_sc).to(device)
         eng.permute(torch.from_numpy(g_pk).to(device).contiguous(), beam)
         eng.step(torch.from_numpy(g_ac).to(device).view(-1).contiguous())
-    print(f"{name}: steps {nsteps}, groups {G}, well-separated mismatches dense {mism_dense} compact {mism_compact}, "
-          f"max |score err| {max_score_err:.2e}")
+    print(f"{name}: steps {nsteps}, groups {G}, well-separated positions {n_sep} of {nsteps * G * beam}, mismatches "
+          f"dense {mism_dense} compact {mism_compact}, max |score err| {max_score_err:.2e}")
+    assert n_sep > nsteps * G * beam // 4
     assert mism_dense == 0 and mism_compact == 0
-    assert max_score_err < 5e-3
+    # log-probabilities of rows of 101 / 202 tokens inherit the logits' tolerance (1e-3 of the row's largest logit)
+    assert max_score_err < (1e-2 if "k100" in name else 5e-3)
     # final state equals the reference's tours
     key = "tour" if "tour" in case else "nodes"
     mine = (eng.state["tour"] if key == "tour" else eng.state["nodes"]).cpu().numpy()
@@ -85,7 +101,8 @@ def test_teacher_forced_beam_steps(name, device):
     np.testing.assert_allclose(length, case["length"], rtol=3e-6)
 
 
-@pytest.mark.parametrize("name", ["tsp_n200_b2_beam8_nn", "cvrp_n150_b2_beam8_nn"])
+@pytest.mark.parametrize("name", ["tsp_n200_b2_beam8_nn", "cvrp_n150_b2_beam8_nn",
+                                  "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn"])
 def test_free_running_beam_rollout_trained(name, device):
     case, eng, pol, beam, A, start = _setup(name, device)
     length = eng.beam_rollout(pol, start, beam).cpu().numpy()
