@@ -111,12 +111,27 @@ def test_more_than_64_candidates(device, N):
     _run_case(device, xy, order, 30, check_until=25)
 
 
-def test_large_n(device):
+@pytest.mark.parametrize("N,until", [(5000, 40), (18512, 10)])
+def test_large_n(device, N, until):
+    """18512 nodes: the largest instance of the reference's TSPLIB table (d18512, utils/utils.py:47-125)."""
     rng = np.random.default_rng(5)
-    N = 5000
     xy = rng.random((1, N, 2), dtype=np.float32)
     order = rng.permutation(N)[None]
-    _run_case(device, xy, order, 30, check_until=40)
+    _run_case(device, xy, order, 30, check_until=until)
+
+
+def test_reset_size_limit(device):
+    """The reset stages an instance's coordinates in LDS: 19200 nodes fit, one more is refused with a message."""
+    import ctypes
+    from dgl_amd import _lib
+    from dgl_amd.engine import TspEngine
+    eng = TspEngine(torch.rand(1, 19200, 2, device=device), 1, 30)
+    eng.reset()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.state["avg"]).all() and (eng.state["sd"] > 0).all()
+    big = TspEngine(torch.rand(1, 19201, 2, device=device), 1, 30)
+    assert _lib.load().dgl_tsp_reset(ctypes.byref(big.state["struct"]), 0) == -1
+    assert b"19200" in _lib.load().dgl_last_error_string()
 
 
 def test_bad_arguments(device):
