@@ -586,44 +586,56 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
     __syncthreads();
     ASTAMP(4);
     const float unscale = 1.0f / sa;
-    const bool full_rows = i0 + 32 <= a.M;
     f32x16 acc = zero16();
-    float other[16], gate[16], bias_j = 0.0f, pmax[3] = {0.0f, 0.0f, 0.0f};
+    // The products are evaluated transposed - the weight fragment as the A operand, the activation rows as B - so that
+    // in the accumulator layout (lane = column) a lane holds 16 output features of ONE token, four consecutive ones
+    // per register group: the epilogue reads and writes 16 bytes per lane and instruction (4 stores per tile instead
+    // of 16, and as many fewer loads of the residual and the gate).  Same products, same order of summation.
+    const int row = i0 + q;                                     // this lane's token
+    const bool row_ok = row < a.M;
+    const long row_c = min(row, a.M - 1);                       // (a valid address for the loads of rows beyond M)
+    float4 other[4], gate[4], bias4[4];
+    float pmax[3] = {0.0f, 0.0f, 0.0f};
     // one chunk: eight k-steps from registers `b`, the next chunk's loads issued first
     auto chunk = [&](int g, u32x4 (&b)[16], u32x4 (&bn)[16]) {
         if (g + 1 < G) load_chunk(bn, g + 1);
         const int c = g % CH, seg = (g / CH) % a.nseg, tile = g / (CH * a.nseg);
         const AwProduct P = a.p[tile / tpp];          // (a copy in registers: a reference is re-read field by field after every store)
-        const int j = 32 * (w + 4 * (tile % tpp)) + q;
+        const int cb = 32 * (w + 4 * (tile % tpp)) + 4 * h;     // this lane's columns: cb + 8 g + {0..3}, g = 0..3
         const bool last = c == CH - 1 && seg == a.nseg - 1;
         if (c == 0 && seg == 0) acc = zero16();
         if (last) {
             // what the epilogue combines with the product, in flight during the last MFMAs (and all of it before the
             // first store: C, add and gate may alias as far as the compiler can tell)
-            bias_j = (P.mode == 0 && P.bias) ? P.bias[j] : 0.0f;
+            const float4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f}, one4 = {1.0f, 1.0f, 1.0f, 1.0f};
+            const bool has_bias = P.mode == 0 && P.bias != nullptr;
+            if (has_bias && (reinterpret_cast<size_t>(P.bias) & 15) == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias4[e] = *reinterpret_cast<const float4 *>(P.bias + cb + 8 * e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *pb = P.bias + cb + 8 * e;
+                    bias4[e] = has_bias ? float4{pb[0], pb[1], pb[2], pb[3]} : zero4;
+                }
+            }
             const float *src = P.mode == 1 ? P.C : P.add;
             const int lds_ = P.mode == 1 ? P.ldc : P.ldadd;
             const bool has_other = P.mode == 1 || P.add != nullptr, has_gate = P.mode == 0 && P.gate != nullptr;
-            // (uniform branches: a guard per row and lane would turn every load into a branch of its own)
-            if (has_other && full_rows) {
+            // (uniform branches: a guard per lane would turn every load into a branch of its own)
+            if (has_other) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) other[r] = src[(long)(i0 + (r & 3) + 8 * (r >> 2) + 4 * h) * lds_ + j];
+                for (int e = 0; e < 4; ++e) other[e] = *reinterpret_cast<const float4 *>(src + row_c * lds_ + cb + 8 * e);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    other[r] = (has_other && i < a.M) ? src[(long)i * lds_ + j] : 0.0f;
-                }
+                for (int e = 0; e < 4; ++e) other[e] = zero4;
             }
-            if (has_gate && full_rows) {
+            if (has_gate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gate[r] = P.gate[(long)(i0 + (r & 3) + 8 * (r >> 2) + 4 * h) * P.ldc + j];
+                for (int e = 0; e < 4; ++e) gate[e] = *reinterpret_cast<const float4 *>(P.gate + row_c * P.ldc + cb + 8 * e);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    gate[r] = (has_gate && i < a.M) ? P.gate[(long)i * P.ldc + j] : 1.0f;
-                }
+                for (int e = 0; e < 4; ++e) gate[e] = one4;
             }
         }
         const _Float16 *Ah = aw_lds + seg * 2 * 32 * LDA + q * LDA + 128 * c + 8 * h, *Al = Ah + 32 * LDA;
@@ -631,9 +643,9 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
         for (int t = 0; t < 8; ++t) {
             const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ah + 16 * t), al = *reinterpret_cast<const f16x8 *>(Al + 16 * t);
             const f16x8 bh = as_f16x8(b[2 * t]), bl = as_f16x8(b[2 * t + 1]);
-            acc = MFMA16(al, bh, acc);
-            acc = MFMA16(ah, bl, acc);
-            acc = MFMA16(ah, bh, acc);
+            acc = MFMA16(bh, al, acc);
+            acc = MFMA16(bl, ah, acc);
+            acc = MFMA16(bh, ah, acc);
         }
 #ifdef GEMM_STAMPS
         if (last && tile < 4) ASTAMP(5 + 2 * tile);
@@ -642,23 +654,30 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
             // (the product's fields in registers before the first store: after a store through a float pointer the
             // compiler re-reads every field it needs from the argument segment, one scalar round trip each)
             float *const C = P.C;
-            const int ldc = P.ldc, rows = a.M;
+            const int ldc = P.ldc;
             const bool plain = P.mode == 0, relu = P.relu != 0;
             float cmax = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!full_rows && i >= rows) continue;
-                float v = acc[r] * unscale;
-                if (plain) {
-                    v += bias_j;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    if (!(gate[r] > 0.0f)) v = 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                const float ov[4] = {other[e].x, other[e].y, other[e].z, other[e].w};
+                const float gv[4] = {gate[e].x, gate[e].y, gate[e].z, gate[e].w};
+                const float bv[4] = {bias4[e].x, bias4[e].y, bias4[e].z, bias4[e].w};
+                float o[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float v = acc[4 * e + m] * unscale;
+                    if (plain) {
+                        v += bv[m];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        if (!(gv[m] > 0.0f)) v = 0.0f;
+                    }
+                    v = ov[m] + v;
+                    o[m] = v;
+                    cmax = fmaxf(cmax, fabsf(v));
                 }
-                v = other[r] + v;
-                C[(long)i * ldc + j] = v;
-                cmax = fmaxf(cmax, fabsf(v));
+                if (row_ok) *reinterpret_cast<float4 *>(C + (long)row * ldc + cb + 8 * e) = float4{o[0], o[1], o[2], o[3]};
             }
+            if (!row_ok) cmax = 0.0f;
 #pragma unroll
             for (int pi = 0; pi < 3; ++pi)
                 if (pi == tile / tpp) pmax[pi] = fmaxf(pmax[pi], cmax);
