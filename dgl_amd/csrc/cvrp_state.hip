@@ -5,6 +5,8 @@
 // One wave64 owns one row.  Nodes 0..N (0 = depot), M = N + 1 points per instance.  The
 // feasibility mask of the reference (ninf_mask [R][M], CVRP/CVRPEnv.py:633-637) is not stored:
 // it is capacity + 1e-6 < demand[j], evaluated where needed.
+#include <cstdlib>
+
 #include "common.h"
 #include "select.h"
 #include "state_common.h"
@@ -455,15 +457,28 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
-    const size_t lds_split = (size_t)(per_wave + 512 + 128 + 2 * 4 * 128 + 8) * sizeof(float);
+    // long rows, few of them: eight waves share a row (more loads in flight per CU), as in the TSP launcher
+    static const int force_waves = getenv("DGL_STEP_WAVES") ? atoi(getenv("DGL_STEP_WAVES")) : 0;            // experiments
+    const int waves = force_waves == 4 || force_waves == 8 ? force_waves : (st->N >= 4096 && st->R <= 1024 ? 8 : 4);
+    // behind the row's arrays: lane minima [2][64 waves] | a second search scratch [128] | lists [2][waves][128] | counts
+    const size_t lds_split = (size_t)(per_wave + 2 * 64 * waves + 128 + 2 * waves * 128 + 2 * waves) * sizeof(float);
     if ((st->R < 2048 || st->R >= 8192) && st->N >= 512 && lds_split <= 150 * 1024) {
-        // few rows: four waves share a row
-        if (lds_split > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<4, UPDATE, D3, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
-        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
-                           *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                           per_wave, link);
+        // few rows: four (or eight) waves share a row
+        if (waves == 8) {
+            if (lds_split > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<8, UPDATE, D3, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+            hipLaunchKernelGGL((cvrp_step_kernel<8, UPDATE, D3, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
+                               *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                               per_wave, link);
+        } else {
+            if (lds_split > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<4, UPDATE, D3, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+            hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                               *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
+                               per_wave, link);
+        }
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
         hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,

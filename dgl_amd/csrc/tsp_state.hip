@@ -119,7 +119,12 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
     // shared-row shape, rows of up to 2048 nodes: 8 N more bytes of LDS hold the new (avg, sd) pairs
     static const int force_mom = getenv("DGL_STEP_MOM") ? atoi(getenv("DGL_STEP_MOM")) : -1;                // experiments
     const bool with_mom = UPDATE && (force_mom >= 0 ? force_mom != 0 : st->N <= 2048);
-    const int split_floats = per_wave + 4 * (64 + 128) + 4;
+    // long rows, few of them: eight waves share a row (more loads in flight per CU: the scan of a 10 000-node row
+    // is bandwidth-bound, and four waves per row leave a CU with eight waves at 512 rows)
+    static const int force_waves = getenv("DGL_STEP_WAVES") ? atoi(getenv("DGL_STEP_WAVES")) : 0;            // experiments
+    // (measured: 512 x 10 000 nodes 27 -> 25 us, 64 x 18 512 nodes 29 -> 20 us; no gain at 2 500 nodes, 16 waves lose)
+    const int waves = force_waves == 4 || force_waves == 8 ? force_waves : (st->N >= 4096 && st->R <= 1024 ? 8 : 4);
+    const int split_floats = per_wave + waves * (64 + 128) + waves;
     const int mom_off = with_mom ? (split_floats + 1) & ~1 : 0;
     const size_t lds_split = (size_t)(with_mom ? mom_off + 2 * st->N : split_floats) * sizeof(float);
     static const int force_split = getenv("DGL_STEP_SPLIT") ? atoi(getenv("DGL_STEP_SPLIT")) : -1;   // experiments
@@ -131,7 +136,13 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
             (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
         static const int force_stream = getenv("DGL_STEP_STREAM") ? atoi(getenv("DGL_STEP_STREAM")) : -1;          // experiments
-        if (with_mom && lds_split <= 48 * 1024 && (force_stream >= 0 ? force_stream != 0 : (long long)st->R * st->N >= 16000000ll))
+        if (waves == 8) {
+            if (lds_split > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)tsp_step_kernel<8, UPDATE, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+            hipLaunchKernelGGL((tsp_step_kernel<8, UPDATE, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
+                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+        } else if (with_mom && lds_split <= 48 * 1024 && (force_stream >= 0 ? force_stream != 0 : (long long)st->R * st->N >= 16000000ll))
             hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true, true>), dim3(st->R), dim3(256), lds_split,
                                (hipStream_t)stream, *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
         else
