@@ -86,8 +86,23 @@ def load_checkpoint_into(model, path):
     model.load_state_dict(ck["model_state_dict"])
 
 
+def _draw_points(B, N, dist):
+    """Node coordinates: uniform in the unit square (TSP/TSPEnv.py:29-32), or - the reference's clustered / explosion /
+    implosion test sets are files that are not shipped - seven Gaussian clusters per instance (sigma 0.04) clipped to
+    the square: tiny distances, where the matrix-product distance formula is least accurate, and exact duplicates on
+    the border."""
+    import torch
+    if dist == "uniform":
+        return torch.rand(B, N, 2)
+    assert dist == "clustered"
+    centres = torch.rand(B, 7, 2)
+    which = torch.randint(0, 7, (B, N))
+    pts = centres[torch.arange(B)[:, None], which] + 0.04 * torch.randn(B, N, 2)
+    return pts.clamp_(0.0, 1.0)
+
+
 def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None, out_dir=".",
-            wseed=789, light=False):
+            wseed=789, light=False, dist="uniform"):
     import torch
     TSPModel, TSPEnv, _, _, Beamsearch = _import_reference()
     torch.manual_seed(wseed)
@@ -96,7 +111,7 @@ def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ck
     model.eval()
     model.mode = "test"
     torch.manual_seed(seed)
-    xy = torch.rand(B, N, 2)
+    xy = _draw_points(B, N, dist)
     start = torch.randperm(N)[:pomo]
 
     env = TSPEnv(data_path="", baseline_path="", mode="test", test_mode="pomo_test", aug_size=pomo,
@@ -195,7 +210,7 @@ def gen_tsp(name, seed, B, N, knn, beam=1, pomo=1, full=False, snap_steps=(), ck
 
 
 def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_steps=(), ckpt=None,
-             out_dir=".", wseed=789, light=False):
+             out_dir=".", wseed=789, light=False, dist="uniform"):
     import torch
     _, _, CVRPModel, CVRPEnv, Beamsearch = _import_reference()
     torch.manual_seed(wseed)
@@ -205,7 +220,7 @@ def gen_cvrp(name, seed, B, N, knn, depot_knn, beam=1, pomo=1, full=False, snap_
     model.mode = "test"
     torch.manual_seed(seed)
     depot_xy = torch.rand(B, 2)
-    node_xy = torch.rand(B, N, 2)
+    node_xy = _draw_points(B, N, dist)
     demand = torch.randint(1, 200, size=(B, N)) / 500.0      # CVRP/CVRPEnv.py:42-48 (N not in {20,50})
     start = torch.randperm(N)[:pomo]
 
@@ -317,6 +332,11 @@ TRAINED_CASES = {
     # the headline size: populations large enough for a ">= 99 % identical tours" assertion
     "tsp_n1000_b128_nn_tours": ("tsp", dict(seed=2025, B=128, N=1000, knn=30, light="tours")),
     "cvrp_n1000_b128_nn_tours": ("cvrp", dict(seed=2025, B=128, N=1000, knn=15, depot_knn=15, light="tours")),
+    # the same population size on clustered instances (the reference evaluates clustered / explosion / implosion sets
+    # beside the uniform one, TSP/test.py:131): tiny distances and duplicate points
+    "tsp_n1000_b128_clustered_nn_tours": ("tsp", dict(seed=2026, B=128, N=1000, knn=30, light="tours", dist="clustered")),
+    "cvrp_n1000_b128_clustered_nn_tours": ("cvrp", dict(seed=2026, B=128, N=1000, knn=15, depot_knn=15, light="tours",
+                                                         dist="clustered")),
     "cvrp_n100_b64_nn": ("cvrp", dict(seed=789, B=64, N=100, knn=15, depot_knn=15)),
     "cvrp_n1000_b4_nn": ("cvrp", dict(seed=123, B=4, N=1000, knn=15, depot_knn=15, light=True)),
     "cvrp_n150_b2_beam8_nn": ("cvrp", dict(seed=123, B=2, N=150, knn=15, depot_knn=15, beam=8)),

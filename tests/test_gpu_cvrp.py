@@ -200,7 +200,8 @@ def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
 
 @pytest.mark.parametrize("name,min_identical", [("cvrp_n100_b64_nn", 0.9), ("cvrp_n1000_b4_nn", 0.5),
                                                 ("cvrp_n100_b256_nn_tours", 0.99),
-                                                ("cvrp_n1000_b128_nn_tours", 0.99)])
+                                                ("cvrp_n1000_b128_nn_tours", 0.99),
+                                                ("cvrp_n1000_b128_clustered_nn_tours", 0.8)])
 def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
     from dgl_amd._lib import PROBLEM_CVRP
     from dgl_amd.engine import PackedPolicy

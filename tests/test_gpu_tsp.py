@@ -122,11 +122,17 @@ def test_greedy_rollout_length(name, device):
 
 @pytest.mark.parametrize("name,min_identical", [("tsp_n100_b64_nn", 0.95), ("tsp_n1000_b8_nn", 0.75),
                                                 ("tsp_n100_b512_nn_tours", 0.99),
-                                                ("tsp_n1000_b128_nn_tours", 0.99)])
+                                                ("tsp_n1000_b128_nn_tours", 0.99),
+                                                ("tsp_n1000_b128_clustered_nn_tours", 0.9)])
 def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     """With the trained checkpoint fixture (peaked action distributions) the greedy tours must be
     the reference's own: >= 99 % of instances on the populations (512 instances of 100 nodes, 128 instances of
-    the headline size, 1000 nodes), mean length within 0.01 %.  (The small cases only bound the damage one flipped arg-max can do to the ratio.)"""
+    the headline size, 1000 nodes), mean length within 0.01 %.  (The small cases only bound the damage one flipped arg-max can do to the ratio.)
+    Clustered instances (seven Gaussian clusters of sigma 0.04: the kind of set the reference evaluates beside the
+    uniform one, TSP/test.py:131) are a different matter: the reference's own tours are not reproducible there - moving
+    the reset's mean / std by one ulp, which is what another summation order of torch.mean does, changes a quarter of
+    them (oracle/rounding_sensitivity.py; none of the uniform ones) - so only the mean length is held to 0.01 % and the
+    identical fraction is reported against a loose floor."""
     from dgl_amd.engine import PackedPolicy
     from dgl_amd._lib import PROBLEM_TSP
     case, weights = load_golden(name)

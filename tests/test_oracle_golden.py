@@ -170,3 +170,16 @@ def test_tsp_training_batch_of_the_oracle_against_reference():
     orc.w = O.enable_grad(w)
     probs = O.tsp_train_batch(orc, torch.from_numpy(t["train/aug_xy"]), torch.from_numpy(t["chunk1/aug_solution"]))
     assert np.array_equal(probs.numpy(), t["train/prob"])
+
+
+def test_reference_tours_on_clustered_instances_hang_on_the_last_bit():
+    """Why the >= 99 % identical-tours gate is asserted on uniform populations only (oracle/rounding_sensitivity.py):
+    moving the reset's mean / std by one ulp leaves the uniform instances' tours alone and changes the mean length of
+    the clustered ones by far less than the 0.01 % that is asserted there."""
+    from oracle.rounding_sensitivity import tours_kept
+    kept_u, rel_u = tours_kept("tsp_n1000_b128_nn_tours", 4)
+    kept_c, rel_c = tours_kept("tsp_n1000_b128_clustered_nn_tours", 6)
+    print(f"uniform: {kept_u}/4 tours kept; clustered: {kept_c}/6 kept, mean length moves by {rel_c:.1e}")
+    assert kept_u == 4 and rel_u == 0.0
+    assert rel_c < 1e-3              # (six instances: one changed tour moves their mean by a few 1e-5)
+
