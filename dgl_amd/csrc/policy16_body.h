@@ -431,7 +431,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             for (int rr = 0; rr < ROWS; ++rr) { af[rr] = zero16(); ahA[rr] = zero16(); ahB[rr] = zero16(); }
             // registers of an epilogue in flight
             float v0[ROWS], v1[ROWS], t0[ROWS], t1[ROWS];
-            unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS];
+            unsigned hp[ROWS], lp[ROWS], hq[ROWS], lq[ROWS], lw0[ROWS], lw1[ROWS];
             f32x4 bb[4];
             auto load_bias = [&](int hc) {
 #pragma unroll
@@ -452,10 +452,18 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
                     t1[rr] = minus_half_hi(v1[rr], hq[rr]);
                 } else {
                     lq[rr] = pack_rtz(t0[rr], t1[rr]);
+                    // one LDS store per gap (a second one costs 24 cycles beside an MFMA): the hi pair of steps
+                    // (st - 1, st) goes out at the odd step, its lo pair one step later; both at the last step
                     if constexpr (st & 1) {
                         *reinterpret_cast<u32x2 *>(HH + rr * ROWH + wr + 8 * g) = u32x2{hp[rr], hq[rr]};
-                        *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
+                        if constexpr (st == 7) {
+                            *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * g) = u32x2{lp[rr], lq[rr]};
+                        } else {
+                            lw0[rr] = lp[rr];
+                            lw1[rr] = lq[rr];
+                        }
                     } else {
+                        if constexpr (st >= 2) *reinterpret_cast<u32x2 *>(HL + rr * ROWH + wr + 8 * (g - 1)) = u32x2{lw0[rr], lw1[rr]};
                         hp[rr] = hq[rr];
                         lp[rr] = lq[rr];
                     }
