@@ -28,6 +28,8 @@ __device__ __forceinline__ void fillers(float (&x)[8], unsigned (&u)[4], float (
         if constexpr (KIND == 11) asm volatile("ds_read_b128 %0, %1" : "=v"(*reinterpret_cast<__attribute__((ext_vector_type(4))) float *>(&x[4 * (i & 1)])) : "v"((unsigned)(threadIdx.x * 16 + 4096 * (i & 3))) : "memory");
         if constexpr (KIND == 12) asm volatile("v_and_b32 %0, %1, %2" : "=v"(u[i & 3]) : "v"(u[(i + 1) & 3]), "v"(u[(i + 2) & 3]));
         if constexpr (KIND == 13) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(u[3]) : "v"(u[i & 1]), "v"(u[(i + 1) & 1]));
+        if constexpr (KIND == 14) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i & 3]) : "v"(x[i & 7]), "v"(x[(i + 1) & 7]));
+        if constexpr (KIND == 15) asm volatile("v_cvt_f16_f32_e32 %0, %1" : "=v"(u[i & 3]) : "v"(x[i & 7]));
         if constexpr (KIND == 7) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*reinterpret_cast<double *>(&x[2 * (i & 3)])) : "v"(*reinterpret_cast<double *>(&x[2 * ((i + 1) & 3)])), "v"(*reinterpret_cast<double *>(&x[2 * ((i + 2) & 3)])));
     }
 }
@@ -99,6 +101,8 @@ int main() {
     row<0>("v_add_f32", out, cyc, blocks);
     row<6>("v_max_f32", out, cyc, blocks);
     row<1>("v_cvt_pkrtz_f16_f32", out, cyc, blocks);
+    row<14>("v_cvt_pk_f16_f32", out, cyc, blocks);
+    row<15>("v_cvt_f16_f32", out, cyc, blocks);
     row<2>("v_fma_mix_f32", out, cyc, blocks);
     row<3>("v_max3_f32 |.|", out, cyc, blocks);
     row<4>("v_accvgpr_read_b32", out, cyc, blocks);
