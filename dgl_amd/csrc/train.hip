@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void attn_bwd_kv(const float *__restrict__ Q, const f
     }
 }
 // both halves of the attention backward in one launch: blockIdx.z = 0 computes dQ, 1 computes dK and dV
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+__global__ __launch_bounds__(512, 4) void attn_bwd_kernel(const float *__restrict__ Q, const float *__restrict__ K,
                                                        const float *__restrict__ V, const float *__restrict__ O,
                                                        const float *__restrict__ dO, int n, const float *__restrict__ amax_qkv,
                                                        const float *__restrict__ amax_do, const float *__restrict__ stats,
