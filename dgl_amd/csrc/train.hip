@@ -13,6 +13,7 @@
 #include "policy_layout.h"
 #include "split_f16.h"
 
+#include <cstdlib>
 #include <mutex>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -738,6 +739,178 @@ static void launch_pair(hipStream_t s, GemmLaunch &gl, AwArgs a, int K) {
         (void)hipFuncSetAttribute((const void *)gemm_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
         hipLaunchKernelGGL(gemm_pair_kernel<512>, dim3(gl.blocks + aw_blocks), dim3(256), lds, s, gl.b, a, gl.blocks);
     }
+}
+
+// ------------------------------------------------------------ feed-forward sublayer, forward pass, one launch
+// Y = A + W2 relu(W1 A + b1) + b2 for 32 tokens per workgroup (TSP/TSPModel.py:395-405, CVRP/CVRPModel.py:580-590):
+// the two products of gemm_aw_kernel chained inside the workgroup, the hidden layer passing through LDS instead of
+// memory.  The hidden layer is produced in two halves of 256 features; each half is scaled by the power of two that
+// suits the largest hidden value of these 32 tokens (the bound of the whole tensor is not known before every workgroup
+// has finished), split into an LDS image, and consumed at once as 16 k-steps of the second product, whose sum is
+// scaled back exactly.  The hidden values go to memory only when the caller keeps them for the backward pass.
+//   chunks of weight operands a wave walks through (16 KB each, double-buffered in registers):
+//   W1 tiles w, w + 4 | W2 tile w, k-steps 0-15 | W1 tiles w + 8, w + 12 | W2 tile w, k-steps 16-31
+struct FfArgs {
+    const float *A, *amax_a;            // [M][128] and the bound of its magnitude
+    const _Float16 *W1p, *W2p;          // packed as for gemm_aw_kernel: W1 (K = 128, 512 columns), W2 (K = 512, 128 columns)
+    const float *b1, *b2;
+    float *H, *amax_h;                  // hidden layer [M][512] and its bound, or both NULL (not kept)
+    float *Y, *amax_y;
+    int M;
+};
+#define FF_LD1 (D_MODEL + 8)
+#define FF_LD2 (FF_DIM / 2 + 8)
+#define FF_LDS_BYTES (2 * 32 * FF_LD1 * 2 + 2 * 32 * FF_LD2 * 2 + (FF_DIM + D_MODEL) * 4 + 16)
+__global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
+    extern __shared__ __align__(16) _Float16 ff_lds[];
+    _Float16 *X1h = ff_lds, *X1l = X1h + 32 * FF_LD1, *H2h = X1l + 32 * FF_LD1, *H2l = H2h + 32 * FF_LD2;
+    float *bias = reinterpret_cast<float *>(H2l + 32 * FF_LD2);              // b1 [512], b2 [128]
+    unsigned *wg_max = reinterpret_cast<unsigned *>(bias + FF_DIM + D_MODEL); // largest hidden value of each half
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32;
+    u32x4 b0[16], b1r[16];
+    auto load_chunk = [&](u32x4 (&b)[16], int g) {
+        const u32x4 *p = (g & 2) == 0
+            ? reinterpret_cast<const u32x4 *>(a.W1p) + (long)((8 * (g >> 2) + w + 4 * (g & 1)) * (D_MODEL / 16)) * 2 * 64 + lane
+            : reinterpret_cast<const u32x4 *>(a.W2p) + (long)(w * (FF_DIM / 16) + 8 * (2 * (g >> 2) + (g & 1))) * 2 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b[e] = p[64 * e];
+    };
+    // eight k-steps: weight fragments from registers (A operand), the tokens' image rows from LDS (B operand)
+    auto steps8 = [&](const u32x4 (&b)[16], const _Float16 *Th, const _Float16 *Tl, f32x16 acc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 th = *reinterpret_cast<const f16x8 *>(Th + 16 * t), tl = *reinterpret_cast<const f16x8 *>(Tl + 16 * t);
+            const f16x8 bh = as_f16x8(b[2 * t]), bl = as_f16x8(b[2 * t + 1]);
+            acc = MFMA16(bh, tl, acc);
+            acc = MFMA16(bl, th, acc);
+            acc = MFMA16(bh, th, acc);
+        }
+        return acc;
+    };
+    float sa;
+    {
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
+            const int rr = min(i0 + row, a.M - 1);                        // (rows beyond M: a valid address, scaled by zero below)
+            v[e] = *reinterpret_cast<const float4 *>(a.A + (long)rr * D_MODEL + 4 * c4);
+        }
+        load_chunk(b0, 0);
+        for (int i = tid; i < FF_DIM + D_MODEL; i += 256) bias[i] = i < FF_DIM ? a.b1[i] : a.b2[i - FF_DIM];
+        if (tid < 2) wg_max[tid] = 0u;
+        sa = pow2_scale_for(amax_read(a.amax_a));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
+            const float sr = i0 + row < a.M ? sa : 0.0f;
+            unsigned h0, l0, h1, l1;
+            split2(v[e].x * sr, v[e].y * sr, h0, l0);
+            split2(v[e].z * sr, v[e].w * sr, h1, l1);
+            *reinterpret_cast<u32x2 *>(X1h + row * FF_LD1 + 4 * c4) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(X1l + row * FF_LD1 + 4 * c4) = u32x2{l0, l1};
+        }
+    }
+    __syncthreads();
+    const float unscale_a = 1.0f / sa;
+    const int row = i0 + q;                                               // this lane's token
+    const bool row_ok = row < a.M;
+    const long row_c = min(row, a.M - 1);
+    float *const Hout = a.H;
+    float *const Yout = a.Y;
+    const _Float16 *X1hq = X1h + q * FF_LD1 + 8 * h, *X1lq = X1l + q * FF_LD1 + 8 * h;
+    const _Float16 *H2hq = H2h + q * FF_LD2 + 8 * h, *H2lq = H2l + q * FF_LD2 + 8 * h;
+    f32x16 y = zero16();
+    float hmax = 0.0f;
+    float4 resid[4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        // hidden features 256 hf + 32 (w + 4 j) + ..., j = 0, 1
+        load_chunk(b1r, 4 * hf + 1);
+        f32x16 t[2];
+        t[0] = steps8(b0, X1hq, X1lq, zero16());
+        load_chunk(b0, 4 * hf + 2);
+        t[1] = steps8(b1r, X1hq, X1lq, zero16());
+        load_chunk(b1r, 4 * hf + 3);
+        float lmax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cb = 256 * hf + 32 * (w + 4 * j) + 4 * h;           // this lane's features: cb + 8 g + {0..3}
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + cb + 8 * g);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                float o[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float v = t[j][4 * g + m] * unscale_a;
+                    v += bv[m];
+                    v = fmaxf(v, 0.0f);
+                    o[m] = row_ok ? v : 0.0f;
+                    lmax = fmaxf(lmax, o[m]);
+                    t[j][4 * g + m] = o[m];
+                }
+                if (Hout != nullptr && row_ok) *reinterpret_cast<float4 *>(Hout + (long)row * FF_DIM + cb + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+            }
+        }
+        lmax = wave_max_f32(lmax);
+        hmax = fmaxf(hmax, lmax);
+        if (lane == 0) atomicMax(&wg_max[hf], __float_as_uint(lmax));
+        __syncthreads();                       // (every wave is past the previous half's second product: the image is free)
+        const float sh = pow2_scale_for(__uint_as_float(wg_max[hf]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h0, l0, h1, l1;
+                split2(t[j][4 * g] * sh, t[j][4 * g + 1] * sh, h0, l0);
+                split2(t[j][4 * g + 2] * sh, t[j][4 * g + 3] * sh, h1, l1);
+                const int lc = 32 * (w + 4 * j) + 8 * g + 4 * h;
+                *reinterpret_cast<u32x2 *>(H2h + q * FF_LD2 + lc) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2 *>(H2l + q * FF_LD2 + lc) = u32x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        if (hf == 1) {
+            // the residual, in flight during the last MFMAs
+#pragma unroll
+            for (int g = 0; g < 4; ++g) resid[g] = *reinterpret_cast<const float4 *>(a.A + row_c * D_MODEL + 32 * w + 4 * h + 8 * g);
+        }
+        f32x16 part = steps8(b0, H2hq, H2lq, zero16());
+        if (hf == 0) load_chunk(b0, 4);
+        part = steps8(b1r, H2hq + 128, H2lq + 128, part);
+        const float unscale_h = 1.0f / sh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] += part[e] * unscale_h;
+    }
+    float ymax = 0.0f;
+    const int cb = 32 * w + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + FF_DIM + cb + 8 * g);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, rv[4] = {resid[g].x, resid[g].y, resid[g].z, resid[g].w};
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float v = y[4 * g + m] + bv[m];
+            v = rv[m] + v;
+            o[m] = v;
+            ymax = fmaxf(ymax, fabsf(v));
+        }
+        if (row_ok) *reinterpret_cast<float4 *>(Yout + (long)row * D_MODEL + cb + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+    }
+    if (!row_ok) ymax = 0.0f;
+    ymax = wave_max_f32(ymax);
+    if (lane == 0) {
+        if (a.amax_y) atomic_max_abs(a.amax_y, ymax);
+        if (a.amax_h) atomic_max_abs(a.amax_h, hmax);
+    }
+}
+// DGL_FF_FUSED=0 keeps the two products of the feed-forward sublayer in separate launches (A/B runs)
+static bool ff_fused_enabled() {
+    static const bool on = [] { const char *e = getenv("DGL_FF_FUSED"); return !(e && atoi(e) == 0); }();
+    return on;
 }
 
 // dst[e] += part[0][e] + part[1][e] + ... (in that order), e < count, rows `stride` floats apart: the ordered sum of the
@@ -1610,6 +1783,13 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0] = aw_product(pk[0][l][3], O1[l], bound(AX_O1 + l), D_MODEL);
             a.p[0].bias = k.bc; a.p[0].add = Xin; a.p[0].ldadd = D_MODEL;
             launch_aw(s, a, D_MODEL);
+        }
+        if (ff_fused_enabled()) {
+            // X[l+1] = O1 + W2 relu(W1 O1 + b1) + b2 in one launch; the hidden layer is kept only for the backward pass
+            FfArgs f{O1[l], bound(AX_O1 + l), pk[0][l][4], pk[0][l][5], k.b1, k.b2, train ? H[l] : nullptr,
+                     train ? bound(AX_H + l) : nullptr, X[l + 1], bound(AX_X + l + 1), M};
+            hipLaunchKernelGGL(ff_fused_kernel, dim3((M + 31) / 32), dim3(256), FF_LDS_BYTES, s, f);
+            continue;
         }
         {   // H = relu(W1 O1 + b1)
             AwArgs a = aw_args(O1[l], bound(AX_O1 + l), D_MODEL, FF_DIM);
