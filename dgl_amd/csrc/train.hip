@@ -741,41 +741,45 @@ static void launch_pair(hipStream_t s, GemmLaunch &gl, AwArgs a, int K) {
     }
 }
 
-// ------------------------------------------------------------ feed-forward sublayer, forward pass, one launch
-// Y = A + W2 relu(W1 A + b1) + b2 for 32 tokens per workgroup (TSP/TSPModel.py:395-405, CVRP/CVRPModel.py:580-590):
-// the two products of gemm_aw_kernel chained inside the workgroup, the hidden layer passing through LDS instead of
-// memory.  The hidden layer is produced in two halves of 256 features; each half is scaled by the power of two that
-// suits the largest hidden value of these 32 tokens (the bound of the whole tensor is not known before every workgroup
-// has finished), split into an LDS image, and consumed at once as 16 k-steps of the second product, whose sum is
-// scaled back exactly.  The hidden values go to memory only when the caller keeps them for the backward pass.
+// ------------------------------------------------------------ a block after its attention, forward pass, one launch
+// O1 = Xin + Wc AO + bc;  Y = O1 + W2 relu(W1 O1 + b1) + b2  for 32 tokens per workgroup (TSP/TSPModel.py:380-405,
+// CVRP/CVRPModel.py:565-590): the three products of gemm_aw_kernel chained inside the workgroup, O1 and the hidden
+// layer passing through LDS instead of memory.  The bound of a whole tensor is not known before every workgroup has
+// finished, so an intermediate operand is scaled by the power of two that suits the largest of its values among these
+// 32 tokens, and the sum is scaled back exactly.  The hidden layer is produced in two halves of 256 features; each
+// half is split into an LDS image and consumed at once as 16 k-steps of the last product.  O1 and the hidden values
+// go to memory only when the caller keeps them for the backward pass; the residual O1 stays in registers (the wave
+// that owns output tile w of the last product owns tile w of O1).
 //   chunks of weight operands a wave walks through (16 KB each, double-buffered in registers):
-//   W1 tiles w, w + 4 | W2 tile w, k-steps 0-15 | W1 tiles w + 8, w + 12 | W2 tile w, k-steps 16-31
+//   Wc tile w | W1 tiles w, w + 4 | W2 tile w, k-steps 0-15 | W1 tiles w + 8, w + 12 | W2 tile w, k-steps 16-31
 struct FfArgs {
-    const float *A, *amax_a;            // [M][128] and the bound of its magnitude
-    const _Float16 *W1p, *W2p;          // packed as for gemm_aw_kernel: W1 (K = 128, 512 columns), W2 (K = 512, 128 columns)
-    const float *b1, *b2;
-    float *H, *amax_h;                  // hidden layer [M][512] and its bound, or both NULL (not kept)
+    const float *AO, *amax_ao;          // attention output [M][128] and the bound of its magnitude
+    const float *Xin;                   // the block's input [M][128]
+    const _Float16 *Wcp, *W1p, *W2p;    // packed as for gemm_aw_kernel: Wc (K = 128, 128 columns), W1 (K = 128, 512), W2 (K = 512, 128)
+    const float *bc, *b1, *b2;
+    float *O1, *amax_o1;                // [M][128] and its bound, or both NULL (not kept)
+    float *H, *amax_h;                  // hidden layer [M][512] and its bound, or both NULL
     float *Y, *amax_y;
     int M;
 };
 #define FF_LD1 (D_MODEL + 8)
 #define FF_LD2 (FF_DIM / 2 + 8)
-#define FF_LDS_BYTES (2 * 32 * FF_LD1 * 2 + 2 * 32 * FF_LD2 * 2 + (FF_DIM + D_MODEL) * 4 + 16)
+#define FF_BIAS_FLOATS (FF_DIM + 2 * D_MODEL)
+#define FF_LDS_BYTES (2 * 32 * FF_LD1 * 2 + 2 * 32 * FF_LD2 * 2 + FF_BIAS_FLOATS * 4 + 16)
 __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
     extern __shared__ __align__(16) _Float16 ff_lds[];
     _Float16 *X1h = ff_lds, *X1l = X1h + 32 * FF_LD1, *H2h = X1l + 32 * FF_LD1, *H2l = H2h + 32 * FF_LD2;
-    float *bias = reinterpret_cast<float *>(H2l + 32 * FF_LD2);              // b1 [512], b2 [128]
-    unsigned *wg_max = reinterpret_cast<unsigned *>(bias + FF_DIM + D_MODEL); // largest hidden value of each half
+    float *bias = reinterpret_cast<float *>(H2l + 32 * FF_LD2);               // b1 [512], b2 [128], bc [128]
+    unsigned *wg_max = reinterpret_cast<unsigned *>(bias + FF_BIAS_FLOATS);   // largest value of: hidden half 0, 1, O1
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
     u32x4 b0[16], b1r[16];
-    auto load_chunk = [&](u32x4 (&b)[16], int g) {
-        const u32x4 *p = (g & 2) == 0
-            ? reinterpret_cast<const u32x4 *>(a.W1p) + (long)((8 * (g >> 2) + w + 4 * (g & 1)) * (D_MODEL / 16)) * 2 * 64 + lane
-            : reinterpret_cast<const u32x4 *>(a.W2p) + (long)(w * (FF_DIM / 16) + 8 * (2 * (g >> 2) + (g & 1))) * 2 * 64 + lane;
+    auto load16 = [&](u32x4 (&b)[16], const u32x4 *p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) b[e] = p[64 * e];
     };
+    auto w1_chunk = [&](int tile) { return reinterpret_cast<const u32x4 *>(a.W1p) + (long)(tile * (D_MODEL / 16)) * 2 * 64 + lane; };
+    auto w2_chunk = [&](int kc) { return reinterpret_cast<const u32x4 *>(a.W2p) + (long)(w * (FF_DIM / 16) + 8 * kc) * 2 * 64 + lane; };
     // eight k-steps: weight fragments from registers (A operand), the tokens' image rows from LDS (B operand)
     auto steps8 = [&](const u32x4 (&b)[16], const _Float16 *Th, const _Float16 *Tl, f32x16 acc) {
 #pragma unroll
@@ -795,12 +799,13 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
             const int rr = min(i0 + row, a.M - 1);                        // (rows beyond M: a valid address, scaled by zero below)
-            v[e] = *reinterpret_cast<const float4 *>(a.A + (long)rr * D_MODEL + 4 * c4);
+            v[e] = *reinterpret_cast<const float4 *>(a.AO + (long)rr * D_MODEL + 4 * c4);
         }
-        load_chunk(b0, 0);
-        for (int i = tid; i < FF_DIM + D_MODEL; i += 256) bias[i] = i < FF_DIM ? a.b1[i] : a.b2[i - FF_DIM];
-        if (tid < 2) wg_max[tid] = 0u;
-        sa = pow2_scale_for(amax_read(a.amax_a));
+        load16(b0, reinterpret_cast<const u32x4 *>(a.Wcp) + (long)(w * (D_MODEL / 16)) * 2 * 64 + lane);
+        for (int i = tid; i < FF_BIAS_FLOATS; i += 256)
+            bias[i] = i < FF_DIM ? a.b1[i] : i < FF_DIM + D_MODEL ? a.b2[i - FF_DIM] : a.bc[i - FF_DIM - D_MODEL];
+        if (tid < 3) wg_max[tid] = 0u;
+        sa = pow2_scale_for(amax_read(a.amax_ao));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
@@ -813,26 +818,68 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         }
     }
     __syncthreads();
-    const float unscale_a = 1.0f / sa;
     const int row = i0 + q;                                               // this lane's token
     const bool row_ok = row < a.M;
     const long row_c = min(row, a.M - 1);
+    float *const O1out = a.O1;
     float *const Hout = a.H;
     float *const Yout = a.Y;
     const _Float16 *X1hq = X1h + q * FF_LD1 + 8 * h, *X1lq = X1l + q * FF_LD1 + 8 * h;
     const _Float16 *H2hq = H2h + q * FF_LD2 + 8 * h, *H2lq = H2l + q * FF_LD2 + 8 * h;
+    const int cbw = 32 * w + 4 * h;                                       // this lane's features of a 128-wide tensor: cbw + 8 g + {0..3}
+    // ---- O1 = Xin + Wc AO + bc: kept in registers as the last product's residual
+    float resid[16];
+    float o1max = 0.0f;
+    {
+        float4 xin[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = *reinterpret_cast<const float4 *>(a.Xin + row_c * D_MODEL + cbw + 8 * g);
+        load16(b1r, w1_chunk(w));
+        const f32x16 acc = steps8(b0, X1hq, X1lq, zero16());
+        load16(b0, w1_chunk(w + 4));
+        const float unscale_a = 1.0f / sa;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias + FF_DIM + D_MODEL + cbw + 8 * g);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, xv[4] = {xin[g].x, xin[g].y, xin[g].z, xin[g].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float v = acc[4 * g + m] * unscale_a;
+                v += bv[m];
+                v = xv[m] + v;
+                v = row_ok ? v : 0.0f;
+                resid[4 * g + m] = v;
+                o1max = fmaxf(o1max, fabsf(v));
+            }
+            if (O1out != nullptr && row_ok)
+                *reinterpret_cast<float4 *>(O1out + (long)row * D_MODEL + cbw + 8 * g) =
+                    float4{resid[4 * g], resid[4 * g + 1], resid[4 * g + 2], resid[4 * g + 3]};
+        }
+        o1max = wave_max_f32(o1max);
+        if (lane == 0) atomicMax(&wg_max[2], __float_as_uint(o1max));
+    }
+    __syncthreads();                           // (every wave has read the attention output's image: O1's image takes its place)
+    const float s1 = pow2_scale_for(__uint_as_float(wg_max[2]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned h0, l0, h1, l1;
+        split2(resid[4 * g] * s1, resid[4 * g + 1] * s1, h0, l0);
+        split2(resid[4 * g + 2] * s1, resid[4 * g + 3] * s1, h1, l1);
+        *reinterpret_cast<u32x2 *>(X1h + q * FF_LD1 + cbw + 8 * g) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(X1l + q * FF_LD1 + cbw + 8 * g) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    const float unscale_1 = 1.0f / s1;
     f32x16 y = zero16();
     float hmax = 0.0f;
-    float4 resid[4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         // hidden features 256 hf + 32 (w + 4 j) + ..., j = 0, 1
-        load_chunk(b1r, 4 * hf + 1);
         f32x16 t[2];
-        t[0] = steps8(b0, X1hq, X1lq, zero16());
-        load_chunk(b0, 4 * hf + 2);
-        t[1] = steps8(b1r, X1hq, X1lq, zero16());
-        load_chunk(b1r, 4 * hf + 3);
+        t[0] = steps8(b1r, X1hq, X1lq, zero16());
+        load16(b1r, w2_chunk(2 * hf));
+        t[1] = steps8(b0, X1hq, X1lq, zero16());
+        load16(b0, w2_chunk(2 * hf + 1));
         float lmax = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -844,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
                 float o[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    float v = t[j][4 * g + m] * unscale_a;
+                    float v = t[j][4 * g + m] * unscale_1;
                     v += bv[m];
                     v = fmaxf(v, 0.0f);
                     o[m] = row_ok ? v : 0.0f;
@@ -857,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         lmax = wave_max_f32(lmax);
         hmax = fmaxf(hmax, lmax);
         if (lane == 0) atomicMax(&wg_max[hf], __float_as_uint(lmax));
-        __syncthreads();                       // (every wave is past the previous half's second product: the image is free)
+        __syncthreads();                       // (every wave is past the previous half's last product: the image is free)
         const float sh = pow2_scale_for(__uint_as_float(wg_max[hf]));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -872,42 +919,38 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
             }
         }
         __syncthreads();
-        if (hf == 1) {
-            // the residual, in flight during the last MFMAs
-#pragma unroll
-            for (int g = 0; g < 4; ++g) resid[g] = *reinterpret_cast<const float4 *>(a.A + row_c * D_MODEL + 32 * w + 4 * h + 8 * g);
-        }
-        f32x16 part = steps8(b0, H2hq, H2lq, zero16());
-        if (hf == 0) load_chunk(b0, 4);
-        part = steps8(b1r, H2hq + 128, H2lq + 128, part);
+        f32x16 part = steps8(b1r, H2hq, H2lq, zero16());
+        if (hf == 0) load16(b1r, w1_chunk(w + 8));
+        part = steps8(b0, H2hq + 128, H2lq + 128, part);
+        if (hf == 0) load16(b0, w1_chunk(w + 12));
         const float unscale_h = 1.0f / sh;
 #pragma unroll
         for (int e = 0; e < 16; ++e) y[e] += part[e] * unscale_h;
     }
     float ymax = 0.0f;
-    const int cb = 32 * w + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4 *>(bias + FF_DIM + cb + 8 * g);
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, rv[4] = {resid[g].x, resid[g].y, resid[g].z, resid[g].w};
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + FF_DIM + cbw + 8 * g);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
         float o[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float v = y[4 * g + m] + bv[m];
-            v = rv[m] + v;
+            v = resid[4 * g + m] + v;
             o[m] = v;
             ymax = fmaxf(ymax, fabsf(v));
         }
-        if (row_ok) *reinterpret_cast<float4 *>(Yout + (long)row * D_MODEL + cb + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+        if (row_ok) *reinterpret_cast<float4 *>(Yout + (long)row * D_MODEL + cbw + 8 * g) = float4{o[0], o[1], o[2], o[3]};
     }
     if (!row_ok) ymax = 0.0f;
     ymax = wave_max_f32(ymax);
     if (lane == 0) {
         if (a.amax_y) atomic_max_abs(a.amax_y, ymax);
         if (a.amax_h) atomic_max_abs(a.amax_h, hmax);
+        if (a.amax_o1) atomic_max_abs(a.amax_o1, o1max);
     }
 }
-// DGL_FF_FUSED=0 keeps the two products of the feed-forward sublayer in separate launches (A/B runs)
+// DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs)
 static bool ff_fused_enabled() {
     static const bool on = [] { const char *e = getenv("DGL_FF_FUSED"); return !(e && atoi(e) == 0); }();
     return on;
@@ -1778,18 +1821,20 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         }
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(R, HEADS), dim3(64 * NT), attn_fwd_lds, s, Qb[l], Kb[l], Vb[l], n, bound(AX_QKV + 3 * l), P[l],
                            AO[l], bound(AX_AO + l));
+        if (ff_fused_enabled()) {
+            // O1 = Xin + Wc AO + bc and X[l+1] = O1 + W2 relu(W1 O1 + b1) + b2 in one launch; O1 and the hidden layer are
+            // kept only for the backward pass
+            FfArgs f{AO[l], bound(AX_AO + l), Xin, pk[0][l][3], pk[0][l][4], pk[0][l][5], k.bc, k.b1, k.b2,
+                     train ? O1[l] : nullptr, train ? bound(AX_O1 + l) : nullptr, train ? H[l] : nullptr,
+                     train ? bound(AX_H + l) : nullptr, X[l + 1], bound(AX_X + l + 1), M};
+            hipLaunchKernelGGL(ff_fused_kernel, dim3((M + 31) / 32), dim3(256), FF_LDS_BYTES, s, f);
+            continue;
+        }
         {   // O1 = Xin + Wc AO + bc
             AwArgs a = aw_args(AO[l], bound(AX_AO + l), D_MODEL, D_MODEL);
             a.p[0] = aw_product(pk[0][l][3], O1[l], bound(AX_O1 + l), D_MODEL);
             a.p[0].bias = k.bc; a.p[0].add = Xin; a.p[0].ldadd = D_MODEL;
             launch_aw(s, a, D_MODEL);
-        }
-        if (ff_fused_enabled()) {
-            // X[l+1] = O1 + W2 relu(W1 O1 + b1) + b2 in one launch; the hidden layer is kept only for the backward pass
-            FfArgs f{O1[l], bound(AX_O1 + l), pk[0][l][4], pk[0][l][5], k.b1, k.b2, train ? H[l] : nullptr,
-                     train ? bound(AX_H + l) : nullptr, X[l + 1], bound(AX_X + l + 1), M};
-            hipLaunchKernelGGL(ff_fused_kernel, dim3((M + 31) / 32), dim3(256), FF_LDS_BYTES, s, f);
-            continue;
         }
         {   // H = relu(W1 O1 + b1)
             AwArgs a = aw_args(O1[l], bound(AX_O1 + l), D_MODEL, FF_DIM);
