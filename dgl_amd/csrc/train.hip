@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define HEADS 8
@@ -950,6 +951,193 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         if (a.amax_o1) atomic_max_abs(a.amax_o1, o1max);
     }
 }
+// The same chain backwards, one launch: dH = (dY W2) where H > 0;  dO1 = dY + dH W1;  dAO = dO1 Wc  (dY the gradient of
+// the block's output).  All three go to memory: the weight gradients and the attention backward read them.
+//   chunks: W2^T tiles w, w + 4 | W1^T tile w, k-steps 0-15 | W2^T tiles w + 8, w + 12 | W1^T tile w, k-steps 16-31 | Wc^T tile w
+struct FfBwdArgs {
+    const float *dY, *amax_dy;          // [M][128] and the bound of its magnitude
+    const float *H;                     // the forward pass's hidden layer [M][512]: the ReLU's gate
+    const _Float16 *W2p, *W1p, *Wcp;    // packed transposed weights: W2 (K = 128, 512 columns), W1 (K = 512, 128), Wc (K = 128, 128)
+    float *dH, *amax_dh;                // [M][512]
+    float *dO1, *amax_do1;              // [M][128]
+    float *dAO, *amax_dao;              // [M][128]
+    int M;
+};
+__global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
+    extern __shared__ __align__(16) _Float16 ff_lds[];
+    _Float16 *X1h = ff_lds, *X1l = X1h + 32 * FF_LD1, *H2h = X1l + 32 * FF_LD1, *H2l = H2h + 32 * FF_LD2;
+    unsigned *wg_max = reinterpret_cast<unsigned *>(H2l + 32 * FF_LD2);       // largest magnitude of: dH half 0, 1, dO1
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32;
+    u32x4 b0[16], b1r[16];
+    auto load16 = [&](u32x4 (&b)[16], const u32x4 *p) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b[e] = p[64 * e];
+    };
+    auto w2_chunk = [&](int tile) { return reinterpret_cast<const u32x4 *>(a.W2p) + (long)(tile * (D_MODEL / 16)) * 2 * 64 + lane; };
+    auto w1_chunk = [&](int kc) { return reinterpret_cast<const u32x4 *>(a.W1p) + (long)(w * (FF_DIM / 16) + 8 * kc) * 2 * 64 + lane; };
+    auto steps8 = [&](const u32x4 (&b)[16], const _Float16 *Th, const _Float16 *Tl, f32x16 acc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 th = *reinterpret_cast<const f16x8 *>(Th + 16 * t), tl = *reinterpret_cast<const f16x8 *>(Tl + 16 * t);
+            const f16x8 bh = as_f16x8(b[2 * t]), bl = as_f16x8(b[2 * t + 1]);
+            acc = MFMA16(bh, tl, acc);
+            acc = MFMA16(bl, th, acc);
+            acc = MFMA16(bh, th, acc);
+        }
+        return acc;
+    };
+    float sa;
+    {
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
+            const int rr = min(i0 + row, a.M - 1);                        // (rows beyond M: a valid address, scaled by zero below)
+            v[e] = *reinterpret_cast<const float4 *>(a.dY + (long)rr * D_MODEL + 4 * c4);
+        }
+        load16(b1r, w2_chunk(w));
+        load16(b0, w2_chunk(w + 4));
+        if (tid < 3) wg_max[tid] = 0u;
+        sa = pow2_scale_for(amax_read(a.amax_dy));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
+            const float sr = i0 + row < a.M ? sa : 0.0f;
+            unsigned h0, l0, h1, l1;
+            split2(v[e].x * sr, v[e].y * sr, h0, l0);
+            split2(v[e].z * sr, v[e].w * sr, h1, l1);
+            *reinterpret_cast<u32x2 *>(X1h + row * FF_LD1 + 4 * c4) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(X1l + row * FF_LD1 + 4 * c4) = u32x2{l0, l1};
+        }
+    }
+    __syncthreads();
+    const int row = i0 + q;                                               // this lane's token
+    const bool row_ok = row < a.M;
+    const long row_c = min(row, a.M - 1);
+    float *const dHout = a.dH;
+    float *const dO1out = a.dO1;
+    float *const dAOout = a.dAO;
+    const _Float16 *X1hq = X1h + q * FF_LD1 + 8 * h, *X1lq = X1l + q * FF_LD1 + 8 * h;
+    const _Float16 *H2hq = H2h + q * FF_LD2 + 8 * h, *H2lq = H2l + q * FF_LD2 + 8 * h;
+    const int cbw = 32 * w + 4 * h;                                       // this lane's features of a 128-wide tensor: cbw + 8 g + {0..3}
+    const float unscale_a = 1.0f / sa;
+    f32x16 y = zero16();
+    float hmax = 0.0f;
+    float4 resid[4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        // hidden features 256 hf + 32 (w + 4 j) + ..., j = 0, 1
+        f32x16 t[2];
+        float4 gate[2][4];
+        t[0] = steps8(b1r, X1hq, X1lq, zero16());
+        load16(b1r, w1_chunk(2 * hf));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gate[j][g] = *reinterpret_cast<const float4 *>(a.H + row_c * FF_DIM + 256 * hf + 32 * (w + 4 * j) + 4 * h + 8 * g);
+        t[1] = steps8(b0, X1hq, X1lq, zero16());
+        load16(b0, w1_chunk(2 * hf + 1));
+        float lmax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cb = 256 * hf + 32 * (w + 4 * j) + 4 * h;           // this lane's features: cb + 8 g + {0..3}
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float gv[4] = {gate[j][g].x, gate[j][g].y, gate[j][g].z, gate[j][g].w};
+                float o[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float v = t[j][4 * g + m] * unscale_a;
+                    if (!(gv[m] > 0.0f)) v = 0.0f;
+                    o[m] = row_ok ? v : 0.0f;
+                    lmax = fmaxf(lmax, fabsf(o[m]));
+                    t[j][4 * g + m] = o[m];
+                }
+                if (row_ok) *reinterpret_cast<float4 *>(dHout + (long)row * FF_DIM + cb + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+            }
+        }
+        lmax = wave_max_f32(lmax);
+        hmax = fmaxf(hmax, lmax);
+        if (lane == 0) atomicMax(&wg_max[hf], __float_as_uint(lmax));
+        __syncthreads();                       // (every wave is past the previous half's last product: the image is free)
+        const float sh = pow2_scale_for(__uint_as_float(wg_max[hf]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h0, l0, h1, l1;
+                split2(t[j][4 * g] * sh, t[j][4 * g + 1] * sh, h0, l0);
+                split2(t[j][4 * g + 2] * sh, t[j][4 * g + 3] * sh, h1, l1);
+                const int lc = 32 * (w + 4 * j) + 8 * g + 4 * h;
+                *reinterpret_cast<u32x2 *>(H2h + q * FF_LD2 + lc) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2 *>(H2l + q * FF_LD2 + lc) = u32x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        if (hf == 1) {
+            // the residual, in flight during the last MFMAs
+#pragma unroll
+            for (int g = 0; g < 4; ++g) resid[g] = *reinterpret_cast<const float4 *>(a.dY + row_c * D_MODEL + cbw + 8 * g);
+        }
+        f32x16 part = steps8(b1r, H2hq, H2lq, zero16());
+        if (hf == 0) load16(b1r, w2_chunk(w + 8));
+        else load16(b1r, reinterpret_cast<const u32x4 *>(a.Wcp) + (long)(w * (D_MODEL / 16)) * 2 * 64 + lane);
+        part = steps8(b0, H2hq + 128, H2lq + 128, part);
+        if (hf == 0) load16(b0, w2_chunk(w + 12));
+        const float unscale_h = 1.0f / sh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] += part[e] * unscale_h;
+    }
+    // ---- dO1 = dY + dH W1, stored and (scaled for these 32 tokens) turned into the image of the last product
+    float o1max = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float rv[4] = {resid[g].x, resid[g].y, resid[g].z, resid[g].w};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float v = rv[m] + y[4 * g + m];
+            v = row_ok ? v : 0.0f;
+            y[4 * g + m] = v;
+            o1max = fmaxf(o1max, fabsf(v));
+        }
+        if (row_ok) *reinterpret_cast<float4 *>(dO1out + (long)row * D_MODEL + cbw + 8 * g) = float4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+    }
+    o1max = wave_max_f32(o1max);
+    if (lane == 0) atomicMax(&wg_max[2], __float_as_uint(o1max));
+    __syncthreads();                           // (the first product's image has long been read by every wave)
+    const float s1 = pow2_scale_for(__uint_as_float(wg_max[2]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned h0, l0, h1, l1;
+        split2(y[4 * g] * s1, y[4 * g + 1] * s1, h0, l0);
+        split2(y[4 * g + 2] * s1, y[4 * g + 3] * s1, h1, l1);
+        *reinterpret_cast<u32x2 *>(X1h + q * FF_LD1 + cbw + 8 * g) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(X1l + q * FF_LD1 + cbw + 8 * g) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    const f32x16 acc = steps8(b1r, X1hq, X1lq, zero16());
+    const float unscale_1 = 1.0f / s1;
+    float aomax = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            o[m] = acc[4 * g + m] * unscale_1;
+            aomax = fmaxf(aomax, fabsf(o[m]));
+        }
+        if (row_ok) *reinterpret_cast<float4 *>(dAOout + (long)row * D_MODEL + cbw + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+    }
+    if (!row_ok) aomax = 0.0f;
+    aomax = wave_max_f32(aomax);
+    if (lane == 0) {
+        if (a.amax_dh) atomic_max_abs(a.amax_dh, hmax);
+        if (a.amax_do1) atomic_max_abs(a.amax_do1, o1max);
+        if (a.amax_dao) atomic_max_abs(a.amax_dao, aomax);
+    }
+}
 // DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs)
 static bool ff_fused_enabled() {
     static const bool on = [] { const char *e = getenv("DGL_FF_FUSED"); return !(e && atoi(e) == 0); }();
@@ -1647,7 +1835,7 @@ extern "C" int dgl_adam_step(float *params, const float *grads, float *exp_avg, 
 // Workspace (floats), M = R*n tokens:
 //   magnitude bounds [64][16 parts, 128 bytes apart] | T [M][12] | X[0..4] [M][128] (input of block l; X[4] = final) | Ea [2][R][128] (encoder
 //   output at the anchors, before their re-embedding) | per block: Q K V AO O1 [M][128] each, H [M][512], attention row
-//   statistics [R][8][n][2] | backward scratch: dA dA2 dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
+//   statistics [R][8][n][2] | backward scratch: dA dA2 dA3 dB dQ dK dV [M][128] each, dH [M][512] | partial sums of one
 //   block's weight and bias gradients | packed weights
 #define AMAX_SLOTS 64
 #define AMAX_FLOATS (AMAX_SLOTS * AMAX_STRIDE)
@@ -1678,7 +1866,7 @@ static size_t part_floats(int R, int n) {
 static size_t ws_floats(int R, int n) {
     const size_t M = (size_t)R * n;
     const size_t per_block = M * (5 * D_MODEL + FF_DIM) + (size_t)R * HEADS * n * 2;
-    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 5 * M * D_MODEL + 2 * (size_t)R * D_MODEL + 4 * per_block + 6 * M * D_MODEL + M * FF_DIM +
+    return AMAX_FLOATS + M * DGL_TILE_STRIDE + 5 * M * D_MODEL + 2 * (size_t)R * D_MODEL + 4 * per_block + 7 * M * D_MODEL + M * FF_DIM +
            part_floats(R, n) + PACKED_FLOATS;
 }
 extern "C" int64_t dgl_policy_general_workspace_floats(int32_t R, int32_t n) { return (int64_t)ws_floats(R, n); }
@@ -1743,6 +1931,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     }
     float *dA = p; p += MD;
     float *dA2 = p; p += MD;
+    float *dA3 = p; p += MD;
     float *dB = p; p += MD;
     float *dQ = p; p += MD;
     float *dK = p; p += MD;
@@ -1873,6 +2062,39 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         // them shares a launch with the chain's next product.  dA holds the gradient of the block's output, dA2 that
         // of O1 (the batch reading dA runs beside the product writing dA2), and the block's input gradient goes back
         // into dA.
+        if (ff_fused_enabled()) {
+            // dH, dO1 (dA2) and dAO (dB) in one launch; after the attention backward all six weight gradients of the
+            // block beside the product that writes the block's input gradient - into the other of two buffers, since
+            // the gradient of W2 still reads the block's output gradient
+            FfBwdArgs fb{dA, ax_out, H[l], pk[1][l][5], pk[1][l][4], pk[1][l][3], dH, bound(AX_DH + l), dA2, ax_mid, dB, bound(AX_DB + l), M};
+            hipLaunchKernelGGL(ff_bwd_kernel, dim3((M + 31) / 32), dim3(256), FF_LDS_BYTES, s, fb);
+            hipLaunchKernelGGL(attn_bwd_kernel, dim3(R, HEADS, 2), dim3(64 * NT), attn_kv_lds > attn_q_lds ? attn_kv_lds : attn_q_lds, s, Qb[l],
+                               Kb[l], Vb[l], AO[l], dB, n, bound(AX_QKV + 3 * l), bound(AX_DB + l), P[l], dQ, dK, dV, bound(AX_DQKV + 3 * l));
+            float *b2_part = ps.take((float *)g.b2, zm, D_MODEL), *b1_part = ps.take((float *)g.b1, zm, FF_DIM);
+            float *bc_part = ps.take((float *)g.bc, zm, D_MODEL);
+            GemmLaunch gl;
+            gl.add(linear_bwd_w(dA, ax_out, D_MODEL, H[l], bound(AX_H + l), FF_DIM, ps.take((float *)g.w2, zm, D_MODEL * FF_DIM), b2_part, M,
+                                D_MODEL, FF_DIM))
+                .add(linear_bwd_w(dH, ax_h, FF_DIM, O1[l], bound(AX_O1 + l), D_MODEL, ps.take((float *)g.w1, zm, FF_DIM * D_MODEL), b1_part, M,
+                                  FF_DIM, D_MODEL))
+                .add(linear_bwd_w(dA2, ax_mid, D_MODEL, AO[l], bound(AX_AO + l), D_MODEL, ps.take((float *)g.wc, zm, D_MODEL * D_MODEL), bc_part, M,
+                                  D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dQ, ax_q, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wq, zm, D_MODEL * D_MODEL), nullptr, M,
+                                  D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dK, ax_q + AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wk, zm, D_MODEL * D_MODEL),
+                                  nullptr, M, D_MODEL, D_MODEL))
+                .add(linear_bwd_w(dV, ax_q + 2 * AMAX_STRIDE, D_MODEL, Xin, bound(AX_X + l), D_MODEL, ps.take((float *)g.wv, zm, D_MODEL * D_MODEL),
+                                  nullptr, M, D_MODEL, D_MODEL));
+            AwArgs a = aw_args(dQ, ax_q, D_MODEL, D_MODEL);
+            a.A[1] = dK; a.amax_a[1] = ax_q + AMAX_STRIDE;
+            a.A[2] = dV; a.amax_a[2] = ax_q + 2 * AMAX_STRIDE;
+            a.nseg = 3;
+            a.p[0] = aw_product(pk[1][l][0], dA3, bound(AX_DX + l), D_MODEL);
+            a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
+            a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
+            launch_pair(s, gl, a, D_MODEL);
+            std::swap(dA, dA3);
+        } else {
         // X[l+1] = O1 + W2 H + b2;  H = relu(..): dH = (dA W2) where H > 0
         {
             AwArgs a = aw_args(dA, ax_out, D_MODEL, FF_DIM);
@@ -1918,6 +2140,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
             a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
             launch_pair(s, gl, a, D_MODEL);
+        }
         }
         if (l == 1) {
             // dW_a[c][k] += sum_r dA[anchor of row r][c] E[anchor of row r][k]: the rows' anchor tokens are n tokens apart

@@ -308,7 +308,7 @@ DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_w
  * reference.  The workspace is a device array inside the library of DGL_STATIC_WORKSPACE_FLOATS floats (64 MiB,
  * held on every device the library runs on until the process ends), so
  * dgl_policy_general_workspace_floats(io->R, io->n) must not exceed that (about 2000 tokens: 10 rows of 202
- * tokens, 66 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
+ * tokens, 65 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
  * No hipMalloc / hipFree or other allocating call is made.  The first call on a device looks the array's
  * address up (make it outside graph capture).  All calls on one device share the array: calls that overlap in
  * time on one device race.  Arguments and results otherwise exactly as dgl_policy_general. */

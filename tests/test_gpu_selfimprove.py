@@ -55,7 +55,11 @@ def _check_training(tr, g, what):
     print(f"   early steps: likely {rel[:early][likely[:early]].max():.2e}, all {rel[:early].max():.2e}; "
           f"all steps: likely {rel[likely].max():.2e}, all {rel.max():.2e}")
     assert np.median(rel) < 1e-4
-    assert rel[:early][likely[:early]].max() < 2e-4 and rel[:early].max() < 6e-4       # observed 5e-5 and 1.3e-4
+    # Early steps: observed 3e-5 ... 2.2e-4 (likely tokens) and 5e-5 ... 3.9e-4 (all) over builds of the kernels that
+    # differ only in the order of their sums; the reference's own trajectory moves by 3e-5 / 2.4e-4 here when noise of
+    # 3e-7 of a tensor's size is added to its gradients (oracle/training_sensitivity.py, pinned by
+    # tests/test_oracle_golden.py::test_reference_training_trajectory_hangs_on_the_last_bits).
+    assert rel[:early][likely[:early]].max() < 5e-4 and rel[:early].max() < 1e-3
     assert rel[likely].max() < 0.1 and rel.max() < 0.15                                # observed 4e-2
     # Weights: Adam divides every entry's step by the entry's own gradient scale, so an entry whose gradient is
     # rounding noise (units that are almost dead, the last layer's biases whose gradients vanish identically,
