@@ -61,6 +61,7 @@ struct GemmArgs {
 #endif
 #define LDK (GBK + 8)   // halfs per LDS row: 8 of padding (conflict-free 16-byte operand reads)
 #define NG (GBK / 16)   // groups of four elements per thread, operand and stage
+static_assert(GBK == 64, "the LDS block permutation of gemm_tile assumes eight 16-byte blocks per row");
 #define GEMM_LDS_BYTES (4 * 64 * LDK * 2)
 
 // power of two that brings a magnitude bound to [2^10, 2^11): exact scaling, 6 binades of headroom below the
@@ -138,6 +139,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
     // operand whose row index is contiguous: four consecutive rows at k = 32 (e/2) + 2 (tid/16) and at k + 1, so that
     // a (k, k+1) pair of every row splits into one packed word.  The next stage is fetched into registers while the
     // MFMAs of the current one run.
+    // LDS offset of (row, k): the 16-byte blocks of a row are permuted by bits 3..5 of the row number.  The 16-byte
+    // operand reads stay conflict-free (eight consecutive rows share a permutation and lie 9 blocks apart), and the
+    // 4-byte stores of a row-contiguous operand - lanes four rows apart, i.e. 16 banks apart with this row length -
+    // spread over all 32 banks instead of 8 (they were the busiest thing in a weight-gradient workgroup).
+    auto lds_off = [](int row, int k) { return row * LDK + (k ^ (((row >> 3) & 7) << 3)); };
     auto map_m = [&](bool k_fast, int e) { return k_fast ? tid / (GBK / 4) + (1024 / GBK) * e : (tid & 15) * 4; };
     auto map_k = [&](bool k_fast, int e) { return k_fast ? (tid % (GBK / 4)) * 4 : 32 * (e >> 1) + 2 * (tid >> 4) + (e & 1); };
     // splits and stores one group (k-contiguous operand: v0) or one pair of groups (row-contiguous operand: v0 at k, v1 at k + 1)
@@ -146,7 +152,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
             unsigned h0, l0, h1, l1;
             split2(v0.x * s, v0.y * s, h0, l0);
             split2(v0.z * s, v0.w * s, h1, l1);
-            const int o = map_m(true, e) * LDK + map_k(true, e);
+            const int o = lds_off(map_m(true, e), map_k(true, e));
             *reinterpret_cast<u32x2 *>(H + o) = u32x2{h0, h1};
             *reinterpret_cast<u32x2 *>(L + o) = u32x2{l0, l1};
         } else {
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
             for (int c = 0; c < 4; ++c) {
                 unsigned hi, lo;
                 split2(k0v[c] * s, k1v[c] * s, hi, lo);
-                const int o = (map_m(false, e) + c) * LDK + map_k(false, e);
+                const int o = lds_off(map_m(false, e) + c, map_k(false, e));
                 *reinterpret_cast<unsigned *>(H + o) = hi;
                 *reinterpret_cast<unsigned *>(L + o) = lo;
             }
@@ -239,7 +245,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &g, const int i0, const
             const int ksteps = FULL ? GBK / 16 : (min(GBK, k_hi - k0) + 15) / 16;
 #pragma unroll 2
             for (int t = 0; t < ksteps; ++t) {
-                const int oa = (wi + q) * LDK + 16 * t + 8 * h, ob = (wj + q) * LDK + 16 * t + 8 * h;
+                const int oa = lds_off(wi + q, 16 * t + 8 * h), ob = lds_off(wj + q, 16 * t + 8 * h);
                 const f16x8 ah = *reinterpret_cast<const f16x8 *>(AH + oa), al = *reinterpret_cast<const f16x8 *>(AL + oa);
                 const f16x8 bh = *reinterpret_cast<const f16x8 *>(BH + ob), bl = *reinterpret_cast<const f16x8 *>(BL + ob);
                 acc = MFMA16(al, bh, acc);
@@ -2092,7 +2098,13 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0] = aw_product(pk[1][l][0], dA3, bound(AX_DX + l), D_MODEL);
             a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
             a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
-            launch_pair(s, gl, a, D_MODEL);
+            static const bool paired = [] { const char *e = getenv("DGL_GRAD_PAIRED"); return e && atoi(e) != 0; }();
+            if (paired) {
+                launch_pair(s, gl, a, D_MODEL);
+            } else {
+                gl.run(s);
+                launch_aw(s, a, D_MODEL);
+            }
             std::swap(dA, dA3);
         } else {
         // X[l+1] = O1 + W2 H + b2;  H = relu(..): dH = (dA W2) where H > 0
