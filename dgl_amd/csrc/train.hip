@@ -1255,15 +1255,17 @@ __device__ __forceinline__ void stage_head_split(const float *__restrict__ src, 
     for (int item = threadIdx.x; item < n_pad; item += blockDim.x) {
         const int t0 = (item >> 1) * 2, blk = item & 1;
         float a[8], b[8];
-        const float *pa = src + (tok0 + t0) * D_MODEL + hd * HDIM + 8 * blk;
-        const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float4 a0 = t0 < n ? *reinterpret_cast<const float4 *>(pa) : z4, a1 = t0 < n ? *reinterpret_cast<const float4 *>(pa + 4) : z4;
-        const float4 b0 = t0 + 1 < n ? *reinterpret_cast<const float4 *>(pa + D_MODEL) : z4;
-        const float4 b1 = t0 + 1 < n ? *reinterpret_cast<const float4 *>(pa + D_MODEL + 4) : z4;
-        a[0] = a0.x * scale; a[1] = a0.y * scale; a[2] = a0.z * scale; a[3] = a0.w * scale;
-        a[4] = a1.x * scale; a[5] = a1.y * scale; a[6] = a1.z * scale; a[7] = a1.w * scale;
-        b[0] = b0.x * scale; b[1] = b0.y * scale; b[2] = b0.z * scale; b[3] = b0.w * scale;
-        b[4] = b1.x * scale; b[5] = b1.y * scale; b[6] = b1.z * scale; b[7] = b1.w * scale;
+        // (rows beyond n: loaded from the last row and scaled by zero - a guard per lane would turn every 16-byte load
+        // into four guarded 4-byte loads)
+        const float *pa = src + (tok0 + min(t0, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
+        const float *pb = src + (tok0 + min(t0 + 1, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
+        const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 4);
+        const float sa = t0 < n ? scale : 0.0f, sb = t0 + 1 < n ? scale : 0.0f;
+        a[0] = a0.x * sa; a[1] = a0.y * sa; a[2] = a0.z * sa; a[3] = a0.w * sa;
+        a[4] = a1.x * sa; a[5] = a1.y * sa; a[6] = a1.z * sa; a[7] = a1.w * sa;
+        b[0] = b0.x * sb; b[1] = b0.y * sb; b[2] = b0.z * sb; b[3] = b0.w * sb;
+        b[4] = b1.x * sb; b[5] = b1.y * sb; b[6] = b1.z * sb; b[7] = b1.w * sb;
         if (rm_hi) {
             u32x4 ah, al, bh, bl;
 #pragma unroll
@@ -1290,14 +1292,11 @@ __device__ __forceinline__ void stage_head_split(const float *__restrict__ src, 
 }
 // the wave's own 32 rows as a B operand (lane (q, h): columns 8h..8h+7 of row tok0 + 32 tile + q), rows >= n zero
 __device__ __forceinline__ void load_own_rows(const float *__restrict__ src, long tok0, int n, int row, int hd, int h, float (&v)[8]) {
-    if (row < n) {
-        const float *p = src + (tok0 + row) * D_MODEL + hd * HDIM + 8 * h;
-        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-    }
+    const float *p = src + (tok0 + min(row, n - 1)) * D_MODEL + hd * HDIM + 8 * h;     // (unguarded loads, masked afterwards)
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    const bool in = row < n;
+    v[0] = in ? a.x : 0.0f; v[1] = in ? a.y : 0.0f; v[2] = in ? a.z : 0.0f; v[3] = in ? a.w : 0.0f;
+    v[4] = in ? b.x : 0.0f; v[5] = in ? b.y : 0.0f; v[6] = in ? b.z : 0.0f; v[7] = in ? b.w : 0.0f;
 }
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, f16x8 &hi, f16x8 &lo) {
     u32x4 h4, l4;
