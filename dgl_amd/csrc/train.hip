@@ -1248,45 +1248,50 @@ __device__ __forceinline__ int rm_off(int row, int blk) { return row * 16 + ((bl
 #define LOG2E 1.44269502f
 __device__ __forceinline__ float exp2_neg(float t) { return __builtin_amdgcn_exp2f(t); }      // 0 for t = -inf
 
-// stages head hd of src rows tok0 .. tok0 + n - 1 (times scale) into the images that are given (else nullptr)
-__device__ __forceinline__ void stage_head_split(const float *__restrict__ src, long tok0, int n, int n_pad, int hd, float scale,
+// Staging of head hd of src rows tok0 .. tok0 + n - 1 (times scale) into the images that are given (else nullptr), in
+// two parts, so that a kernel can request everything it stages before it waits for any of it (a load placed after
+// the LDS stores of the previous image would start a round trip of its own).  Thread `item` < n_pad takes the pair of
+// tokens 2 (item / 2), + 1 and the 8-column block item % 2: the transposed image takes the pair as one packed word.
+struct HeadRows { float4 a0, a1, b0, b1; };
+__device__ __forceinline__ HeadRows stage_head_load(const float *__restrict__ src, long tok0, int n, int hd) {
+    const int item = threadIdx.x, t0 = (item >> 1) * 2, blk = item & 1;
+    // (rows beyond n: loaded from the last row and scaled by zero - a guard per lane would turn every 16-byte load
+    // into four guarded 4-byte loads)
+    const float *pa = src + (tok0 + min(t0, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
+    const float *pb = src + (tok0 + min(t0 + 1, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
+    return HeadRows{*reinterpret_cast<const float4 *>(pa), *reinterpret_cast<const float4 *>(pa + 4),
+                    *reinterpret_cast<const float4 *>(pb), *reinterpret_cast<const float4 *>(pb + 4)};
+}
+__device__ __forceinline__ void stage_head_store(const HeadRows &r, int n, int n_pad, float scale,
                                                  _Float16 *rm_hi, _Float16 *rm_lo, _Float16 *t_hi, _Float16 *t_lo, int TS) {
-    // item = (pair of tokens 2p, 2p + 1; 8-column block): the transposed image takes the pair as one packed word
-    for (int item = threadIdx.x; item < n_pad; item += blockDim.x) {
-        const int t0 = (item >> 1) * 2, blk = item & 1;
-        float a[8], b[8];
-        // (rows beyond n: loaded from the last row and scaled by zero - a guard per lane would turn every 16-byte load
-        // into four guarded 4-byte loads)
-        const float *pa = src + (tok0 + min(t0, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
-        const float *pb = src + (tok0 + min(t0 + 1, n - 1)) * D_MODEL + hd * HDIM + 8 * blk;
-        const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 4);
-        const float sa = t0 < n ? scale : 0.0f, sb = t0 + 1 < n ? scale : 0.0f;
-        a[0] = a0.x * sa; a[1] = a0.y * sa; a[2] = a0.z * sa; a[3] = a0.w * sa;
-        a[4] = a1.x * sa; a[5] = a1.y * sa; a[6] = a1.z * sa; a[7] = a1.w * sa;
-        b[0] = b0.x * sb; b[1] = b0.y * sb; b[2] = b0.z * sb; b[3] = b0.w * sb;
-        b[4] = b1.x * sb; b[5] = b1.y * sb; b[6] = b1.z * sb; b[7] = b1.w * sb;
-        if (rm_hi) {
-            u32x4 ah, al, bh, bl;
+    const int item = threadIdx.x, t0 = (item >> 1) * 2, blk = item & 1;
+    if (item >= n_pad) return;
+    float a[8], b[8];
+    const float sa = t0 < n ? scale : 0.0f, sb = t0 + 1 < n ? scale : 0.0f;
+    a[0] = r.a0.x * sa; a[1] = r.a0.y * sa; a[2] = r.a0.z * sa; a[3] = r.a0.w * sa;
+    a[4] = r.a1.x * sa; a[5] = r.a1.y * sa; a[6] = r.a1.z * sa; a[7] = r.a1.w * sa;
+    b[0] = r.b0.x * sb; b[1] = r.b0.y * sb; b[2] = r.b0.z * sb; b[3] = r.b0.w * sb;
+    b[4] = r.b1.x * sb; b[5] = r.b1.y * sb; b[6] = r.b1.z * sb; b[7] = r.b1.w * sb;
+    if (rm_hi) {
+        u32x4 ah, al, bh, bl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned hi, lo;
-                split2(a[2 * e], a[2 * e + 1], hi, lo); ah[e] = hi; al[e] = lo;
-                split2(b[2 * e], b[2 * e + 1], hi, lo); bh[e] = hi; bl[e] = lo;
-            }
-            *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0, blk)) = ah;
-            *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0, blk)) = al;
-            *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0 + 1, blk)) = bh;
-            *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0 + 1, blk)) = bl;
+        for (int e = 0; e < 4; ++e) {
+            unsigned hi, lo;
+            split2(a[2 * e], a[2 * e + 1], hi, lo); ah[e] = hi; al[e] = lo;
+            split2(b[2 * e], b[2 * e + 1], hi, lo); bh[e] = hi; bl[e] = lo;
         }
-        if (t_hi) {
+        *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0, blk)) = ah;
+        *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0, blk)) = al;
+        *reinterpret_cast<u32x4 *>(rm_hi + rm_off(t0 + 1, blk)) = bh;
+        *reinterpret_cast<u32x4 *>(rm_lo + rm_off(t0 + 1, blk)) = bl;
+    }
+    if (t_hi) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                unsigned hi, lo;
-                split2(a[e], b[e], hi, lo);
-                *reinterpret_cast<unsigned *>(t_hi + (8 * blk + e) * TS + t0) = hi;
-                *reinterpret_cast<unsigned *>(t_lo + (8 * blk + e) * TS + t0) = lo;
-            }
+        for (int e = 0; e < 8; ++e) {
+            unsigned hi, lo;
+            split2(a[e], b[e], hi, lo);
+            *reinterpret_cast<unsigned *>(t_hi + (8 * blk + e) * TS + t0) = hi;
+            *reinterpret_cast<unsigned *>(t_lo + (8 * blk + e) * TS + t0) = lo;
         }
     }
 }
@@ -1350,13 +1355,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
     _Float16 *Kh = att_lds, *Kl = Kh + n_pad * 16, *VTh = Kl + n_pad * 16, *VTl = VTh + 16 * TS;
     const int r = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x & 63, it = threadIdx.x >> 6, q = lane & 31, h = lane >> 5;
     const long tok0 = (long)r * n;
-    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
-                sv = pow2_scale_for(amax_read(amax_qkv + 2 * AMAX_STRIDE));
-    stage_head_split(K, tok0, n, n_pad, hd, sk, Kh, Kl, nullptr, nullptr, TS);
-    stage_head_split(V, tok0, n, n_pad, hd, sv, nullptr, nullptr, VTh, VTl, TS);
     const int i = 32 * it + q;
+    const HeadRows rk = stage_head_load(K, tok0, n, hd), rv = stage_head_load(V, tok0, n, hd);
     float qv[8];
     load_own_rows(Q, tok0, n, i, hd, h, qv);
+    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
+                sv = pow2_scale_for(amax_read(amax_qkv + 2 * AMAX_STRIDE));
+    stage_head_store(rk, n, n_pad, sk, Kh, Kl, nullptr, nullptr, TS);
+    stage_head_store(rv, n, n_pad, sv, nullptr, nullptr, VTh, VTl, TS);
     f16x8 qh, ql;
     split8(qv, sq, qh, ql);
     __syncthreads();
@@ -1426,16 +1432,19 @@ __device__ __forceinline__ void attn_bwd_q(const float *__restrict__ Q, const fl
     _Float16 *Kh = att_lds, *Kl = Kh + n_pad * 16, *Vh = Kl + n_pad * 16, *Vl = Vh + n_pad * 16, *KTh = Vl + n_pad * 16, *KTl = KTh + 16 * TS;
     const int r = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x & 63, it = threadIdx.x >> 6, q = lane & 31, h = lane >> 5;
     const long tok0 = (long)r * n;
-    const float bound_v = amax_read(amax_qkv + 2 * AMAX_STRIDE);
-    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
-                sv = pow2_scale_for(bound_v), sg = pow2_scale_for(amax_read(amax_do));
-    stage_head_split(K, tok0, n, n_pad, hd, sk, Kh, Kl, KTh, KTl, TS);
-    stage_head_split(V, tok0, n, n_pad, hd, sv, Vh, Vl, nullptr, nullptr, TS);
     const int i = 32 * it + q;
+    const HeadRows rk = stage_head_load(K, tok0, n, hd), rv = stage_head_load(V, tok0, n, hd);
     float qv[8], gv[8], ov[8];
     load_own_rows(Q, tok0, n, i, hd, h, qv);
     load_own_rows(dO, tok0, n, i, hd, h, gv);
     load_own_rows(O, tok0, n, i, hd, h, ov);
+    const float *st = stats + (((long)r * HEADS + hd) * n + min(i, n - 1)) * 2;
+    const float st_max = st[0], st_sum = st[1];
+    const float bound_v = amax_read(amax_qkv + 2 * AMAX_STRIDE);
+    const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
+                sv = pow2_scale_for(bound_v), sg = pow2_scale_for(amax_read(amax_do));
+    stage_head_store(rk, n, n_pad, sk, Kh, Kl, KTh, KTl, TS);
+    stage_head_store(rv, n, n_pad, sv, Vh, Vl, nullptr, nullptr, TS);
     float dt = 0.0f, l1 = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dt = fmaf(gv[e], ov[e], dt); l1 += fabsf(gv[e]); }
@@ -1445,12 +1454,7 @@ __device__ __forceinline__ void attn_bwd_q(const float *__restrict__ Q, const fl
     f16x8 qh, ql, gh, gl;
     split8(qv, sq, qh, ql);
     split8(gv, sg, gh, gl);
-    float mx = 0.0f, inv = 1.0f;
-    if (i < n) {
-        const float *st = stats + (((long)r * HEADS + hd) * n + i) * 2;
-        mx = st[0];
-        inv = 1.0f / st[1];
-    }
+    const float mx = i < n ? st_max : 0.0f, inv = i < n ? 1.0f / st_sum : 1.0f;
     __syncthreads();
     const float cs = 0.25f * LOG2E / (sq * sk), cg = 1.0f / (sv * sg);
     f32x16 dq = zero16();
@@ -1501,35 +1505,39 @@ __device__ __forceinline__ void attn_bwd_kv(const float *__restrict__ Q, const f
     const float sq = pow2_scale_for(amax_read(amax_qkv)), sk = pow2_scale_for(amax_read(amax_qkv + AMAX_STRIDE)),
                 sv = pow2_scale_for(bound_v), sg = pow2_scale_for(amax_read(amax_do));
     if (threadIdx.x == 0) *bound_bits = 0u;
-    stage_head_split(Q, tok0, n, n_pad, hd, sq, Qh, Ql, QTh, QTl, TS);
-    stage_head_split(dO, tok0, n, n_pad, hd, sg, Gh, Gl, GTh, GTl, TS);
-    __syncthreads();
-    {   // per query: row maximum, 1 / row sum, dO.O, and the bound of its dS entries
-        const int t = threadIdx.x;
-        float mxv = 0.0f, iv = 0.0f, d = 0.0f, l1 = 0.0f;
-        if (t < n) {
-            const float *st = stats + (((long)r * HEADS + hd) * n + t) * 2;
-            mxv = st[0];
-            iv = 1.0f / st[1];
-            const float *pg = dO + (tok0 + t) * D_MODEL + hd * HDIM, *po = O + (tok0 + t) * D_MODEL + hd * HDIM;
-#pragma unroll
-            for (int e = 0; e < HDIM; e += 4) {
-                const float4 g4 = *reinterpret_cast<const float4 *>(pg + e), o4 = *reinterpret_cast<const float4 *>(po + e);
-                d = fmaf(g4.x, o4.x, d); d = fmaf(g4.y, o4.y, d); d = fmaf(g4.z, o4.z, d); d = fmaf(g4.w, o4.w, d);
-                l1 += fabsf(g4.x) + fabsf(g4.y) + fabsf(g4.z) + fabsf(g4.w);
-            }
-        }
-        if (t < n_pad) { Mx[t] = mxv; Inv[t] = iv; Dt[t] = d; }           // Inv = 0 beyond n: those rows' P vanish
-        float b = wave_max_f32((l1 * bound_v + fabsf(d)) * 0.25f);
-        if (lane == 0) atomicMax(bound_bits, __float_as_uint(b));
-    }
+    // everything this workgroup reads from memory is requested here, before the first wait
+    const HeadRows rq = stage_head_load(Q, tok0, n, hd), rg = stage_head_load(dO, tok0, n, hd);
     const int j = 32 * jt + q;
     float kv[8], vv[8];
     load_own_rows(K, tok0, n, j, hd, h, kv);
     load_own_rows(V, tok0, n, j, hd, h, vv);
+    float bound_t;
+    {   // per query (thread t): row maximum, 1 / row sum, dO.O, and the bound of its dS entries
+        const int t = threadIdx.x, tc = min(t, n - 1);
+        const float *st = stats + (((long)r * HEADS + hd) * n + tc) * 2;
+        const float st_max = st[0], st_sum = st[1];
+        const float *pg = dO + (tok0 + tc) * D_MODEL + hd * HDIM, *po = O + (tok0 + tc) * D_MODEL + hd * HDIM;
+        float4 g4[HDIM / 4], o4[HDIM / 4];
+#pragma unroll
+        for (int e = 0; e < HDIM / 4; ++e) { g4[e] = *reinterpret_cast<const float4 *>(pg + 4 * e); o4[e] = *reinterpret_cast<const float4 *>(po + 4 * e); }
+        stage_head_store(rq, n, n_pad, sq, Qh, Ql, QTh, QTl, TS);
+        stage_head_store(rg, n, n_pad, sg, Gh, Gl, GTh, GTl, TS);
+        float d = 0.0f, l1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < HDIM / 4; ++e) {
+            d = fmaf(g4[e].x, o4[e].x, d); d = fmaf(g4[e].y, o4[e].y, d); d = fmaf(g4[e].z, o4[e].z, d); d = fmaf(g4[e].w, o4[e].w, d);
+            l1 += fabsf(g4[e].x) + fabsf(g4[e].y) + fabsf(g4[e].z) + fabsf(g4[e].w);
+        }
+        const bool in = t < n;
+        if (!in) { d = 0.0f; l1 = 0.0f; }
+        if (t < n_pad) { Mx[t] = in ? st_max : 0.0f; Inv[t] = in ? 1.0f / st_sum : 0.0f; Dt[t] = d; }   // Inv = 0 beyond n: those rows' P vanish
+        bound_t = wave_max_f32((l1 * bound_v + fabsf(d)) * 0.25f);
+    }
     f16x8 kh, kl, vh, vl;
     split8(kv, sk, kh, kl);
     split8(vv, sv, vh, vl);
+    __syncthreads();                                         // (the bound's zero is visible)
+    if (lane == 0) atomicMax(bound_bits, __float_as_uint(bound_t));
     __syncthreads();
     const float c = pow2_scale_for(__uint_as_float(*bound_bits));
     const float cs = 0.25f * LOG2E / (sq * sk), cg = 1.0f / (sv * sg);
