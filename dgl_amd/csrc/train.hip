@@ -1144,10 +1144,11 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         if (a.amax_dao) atomic_max_abs(a.amax_dao, aomax);
     }
 }
-// DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs)
+// DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs and the test that
+// compares the two; read at every call)
 static bool ff_fused_enabled() {
-    static const bool on = [] { const char *e = getenv("DGL_FF_FUSED"); return !(e && atoi(e) == 0); }();
-    return on;
+    const char *e = getenv("DGL_FF_FUSED");
+    return !(e && atoi(e) == 0);
 }
 
 // dst[e] += part[0][e] + part[1][e] + ... (in that order), e < count, rows `stride` floats apart: the ordered sum of the
@@ -2105,8 +2106,8 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0] = aw_product(pk[1][l][0], dA3, bound(AX_DX + l), D_MODEL);
             a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
             a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
-            static const bool paired = [] { const char *e = getenv("DGL_GRAD_PAIRED"); return e && atoi(e) != 0; }();
-            if (paired) {
+            const char *pe = getenv("DGL_GRAD_PAIRED");
+            if (pe && atoi(pe) != 0) {
                 launch_pair(s, gl, a, D_MODEL);
             } else {
                 gl.run(s);

@@ -107,6 +107,38 @@ def test_cvrp_train_step_matches_autograd(N, knn, kd, device):
     assert torch.equal(prob2, prob) and torch.equal(tr.grads, first), "gradients are not reproducible"
 
 
+@pytest.mark.parametrize("N,knn,kd", [(120, 25, 25), (260, 100, 100)])
+def test_fused_chains_match_separate_launches(N, knn, kd, device, monkeypatch):
+    """Everything after a block's attention runs as one launch per direction; DGL_FF_FUSED=0 and DGL_GRAD_PAIRED=1 keep
+    the earlier sequences of launches.  Same products and sums up to the scaling of intermediate operands (by the
+    largest value of a workgroup's 32 tokens instead of the tensor's) and the order of the hidden layer's two halves:
+    probabilities, logits and gradients agree to rounding."""
+    from dgl_amd._lib import PROBLEM_CVRP
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd.train import PolicyTrainer
+    B = 5
+    w, orc, eng = _cvrp_pair(B, N, knn, kd, device, seed=5 + N)
+    il, _ = orc.knn_indices()
+    teacher = il[torch.arange(B), torch.arange(B) % il.shape[1]].clone()
+    out = {}
+    for name, env in (("fused", {}), ("separate", {"DGL_FF_FUSED": "0"}), ("paired", {"DGL_GRAD_PAIRED": "1"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            tr = PolicyTrainer(w, PROBLEM_CVRP, device)
+            tr.zero_grad()
+            prob = tr.forward_backward(eng, teacher)
+            eng.forward(PackedPolicy(w, PROBLEM_CVRP, device), want_logits=True, want_prob=True)     # the inference forward
+            out[name] = (prob.clone(), tr.grads.double().clone(), eng.logits.clone())
+    n = knn + kd + 2
+    for other in ("separate", "paired"):
+        np.testing.assert_allclose(out["fused"][0].cpu().numpy(), out[other][0].cpu().numpy(), rtol=5e-6)
+        ga, gb = out["fused"][1], out[other][1]
+        assert float((ga - gb).norm() / gb.norm()) < 2e-6
+        la, lb = out["fused"][2][:, :n], out[other][2][:, :n]
+        assert float((la - lb).abs().max() / lb.abs().max()) < 2e-6
+
+
 def test_adam_matches_torch(device):
     from dgl_amd._lib import PROBLEM_TSP
     from dgl_amd.train import PolicyTrainer
