@@ -83,6 +83,15 @@ __device__ __forceinline__ void atomic_max_abs(float *bound, float v) {
     float *slot = bound + (blockIdx.x & (AMAX_SUB - 1)) * AMAX_SUB_STRIDE;
     if (v > *reinterpret_cast<volatile float *>(slot)) atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(v));
 }
+// The same with the read taken earlier (`seen`, by amax_peek): a load placed after a kernel's last stores waits for
+// all of them (loads and stores leave one queue in order), and that wait was the last several thousand cycles of
+// every workgroup; a value read before the stores is at worst staler, which costs an atomic, never a wrong bound.
+__device__ __forceinline__ float amax_peek(const float *bound) {
+    return *reinterpret_cast<const volatile float *>(bound + (blockIdx.x & (AMAX_SUB - 1)) * AMAX_SUB_STRIDE);
+}
+__device__ __forceinline__ void atomic_max_abs_seen(float *bound, float v, float seen) {
+    if (v > seen) atomicMax(reinterpret_cast<unsigned *>(bound + (blockIdx.x & (AMAX_SUB - 1)) * AMAX_SUB_STRIDE), __float_as_uint(v));
+}
 __device__ __forceinline__ float amax_read(const float *bound) {
     float m = 0.0f;
 #pragma unroll
@@ -603,7 +612,7 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
     const bool row_ok = row < a.M;
     const long row_c = min(row, a.M - 1);                       // (a valid address for the loads of rows beyond M)
     float4 other[4], gate[4], bias4[4];
-    float pmax[3] = {0.0f, 0.0f, 0.0f};
+    float pmax[3] = {0.0f, 0.0f, 0.0f}, seen[3] = {0.0f, 0.0f, 0.0f};
     // one chunk: eight k-steps from registers `b`, the next chunk's loads issued first
     auto chunk = [&](int g, u32x4 (&b)[16], u32x4 (&bn)[16]) {
         if (g + 1 < G) load_chunk(bn, g + 1);
@@ -616,6 +625,13 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
             // what the epilogue combines with the product, in flight during the last MFMAs (and all of it before the
             // first store: C, add and gate may alias as far as the compiler can tell)
             const float4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f}, one4 = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (tile % tpp == tpp - 1 && P.amax_c != nullptr) {
+                // the product's last tile of this wave: the bound as it stands, read before the tile's stores
+                const float sv = amax_peek(P.amax_c);
+#pragma unroll
+                for (int pi = 0; pi < 3; ++pi)
+                    if (pi == tile / tpp) seen[pi] = sv;
+            }
             const bool has_bias = P.mode == 0 && P.bias != nullptr;
             if (has_bias && (reinterpret_cast<size_t>(P.bias) & 15) == 0) {
 #pragma unroll
@@ -698,12 +714,12 @@ __device__ __forceinline__ void gemm_aw_block(const AwArgs &a, const int block) 
         chunk(g, b0, b1);
         if (g + 1 < G) chunk(g + 1, b1, b0);
     }
-    // the products' magnitude bounds, once per wave: the read-before-atomic waits for every store issued so far
+    // the products' magnitude bounds, once per wave, against the value read before the last tile's stores
 #pragma unroll
     for (int pi = 0; pi < 3; ++pi) {
         if (pi < a.nprod && a.p[pi].amax_c) {
             const float m = wave_max_f32(pmax[pi]);
-            if (lane == 0) atomic_max_abs(a.p[pi].amax_c, m);
+            if (lane == 0) atomic_max_abs_seen(a.p[pi].amax_c, m, seen[pi]);
         }
     }
     ASTAMP(13);
@@ -837,6 +853,9 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
     // ---- O1 = Xin + Wc AO + bc: kept in registers as the last product's residual
     float resid[16];
     float o1max = 0.0f;
+    // (each bound as it stands is read before the stores of the tensor it belongs to: see amax_peek)
+    const float seen_o1 = a.amax_o1 ? amax_peek(a.amax_o1) : 0.0f;
+    float seen_h = 0.0f;
     {
         float4 xin[4];
 #pragma unroll
@@ -887,6 +906,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         load16(b1r, w2_chunk(2 * hf));
         t[1] = steps8(b0, X1hq, X1lq, zero16());
         load16(b0, w2_chunk(2 * hf + 1));
+        if (hf == 1 && a.amax_h) seen_h = amax_peek(a.amax_h);
         float lmax = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -935,6 +955,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         for (int e = 0; e < 16; ++e) y[e] += part[e] * unscale_h;
     }
     float ymax = 0.0f;
+    const float seen_y = a.amax_y ? amax_peek(a.amax_y) : 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4 *>(bias + FF_DIM + cbw + 8 * g);
@@ -952,9 +973,9 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
     if (!row_ok) ymax = 0.0f;
     ymax = wave_max_f32(ymax);
     if (lane == 0) {
-        if (a.amax_y) atomic_max_abs(a.amax_y, ymax);
-        if (a.amax_h) atomic_max_abs(a.amax_h, hmax);
-        if (a.amax_o1) atomic_max_abs(a.amax_o1, o1max);
+        if (a.amax_y) atomic_max_abs_seen(a.amax_y, ymax, seen_y);
+        if (a.amax_h) atomic_max_abs_seen(a.amax_h, hmax, seen_h);
+        if (a.amax_o1) atomic_max_abs_seen(a.amax_o1, o1max, seen_o1);
     }
 }
 // The same chain backwards, one launch: dH = (dY W2) where H > 0;  dO1 = dY + dH W1;  dAO = dO1 Wc  (dY the gradient of
@@ -1029,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     const int cbw = 32 * w + 4 * h;                                       // this lane's features of a 128-wide tensor: cbw + 8 g + {0..3}
     const float unscale_a = 1.0f / sa;
     f32x16 y = zero16();
-    float hmax = 0.0f;
+    float hmax = 0.0f, seen_h = 0.0f;
     float4 resid[4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -1045,6 +1066,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
                 gate[j][g] = *reinterpret_cast<const float4 *>(a.H + row_c * FF_DIM + 256 * hf + 32 * (w + 4 * j) + 4 * h + 8 * g);
         t[1] = steps8(b0, X1hq, X1lq, zero16());
         load16(b0, w1_chunk(2 * hf + 1));
+        if (hf == 1 && a.amax_dh) seen_h = amax_peek(a.amax_dh);
         float lmax = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1098,6 +1120,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     }
     // ---- dO1 = dY + dH W1, stored and (scaled for these 32 tokens) turned into the image of the last product
     float o1max = 0.0f;
+    const float seen_o1 = a.amax_do1 ? amax_peek(a.amax_do1) : 0.0f, seen_ao = a.amax_dao ? amax_peek(a.amax_dao) : 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float rv[4] = {resid[g].x, resid[g].y, resid[g].z, resid[g].w};
@@ -1139,9 +1162,9 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     if (!row_ok) aomax = 0.0f;
     aomax = wave_max_f32(aomax);
     if (lane == 0) {
-        if (a.amax_dh) atomic_max_abs(a.amax_dh, hmax);
-        if (a.amax_do1) atomic_max_abs(a.amax_do1, o1max);
-        if (a.amax_dao) atomic_max_abs(a.amax_dao, aomax);
+        if (a.amax_dh) atomic_max_abs_seen(a.amax_dh, hmax, seen_h);
+        if (a.amax_do1) atomic_max_abs_seen(a.amax_do1, o1max, seen_o1);
+        if (a.amax_dao) atomic_max_abs_seen(a.amax_dao, aomax, seen_ao);
     }
 }
 // DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs and the test that
@@ -1405,6 +1428,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
     }
     sum += __shfl_xor(sum, 32, 64);
     float omax = 0.0f;
+    const float seen_o = amax_peek(amax_o);
     if (i < n) {
         omax = store_head_rows(O + (tok0 + i) * D_MODEL + hd * HDIM, o, 1.0f / (1024.0f * sv * sum), h);
         if (h == 0) {
@@ -1414,7 +1438,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float *__restrict__
         }
     }
     omax = wave_max_f32(omax);
-    if (lane == 0) atomic_max_abs(amax_o, omax);
+    if (lane == 0) atomic_max_abs_seen(amax_o, omax, seen_o);
 }
 
 // Backward of the above.  dO, O [M][128] -> dQ, dK, dV [M][128].
@@ -1481,9 +1505,10 @@ __device__ __forceinline__ void attn_bwd_q(const float *__restrict__ Q, const fl
         }
     }
     float m = 0.0f;
+    const float seen_dq = amax_peek(amax_dq);
     if (i < n) m = store_head_rows(dQ + (tok0 + i) * D_MODEL + hd * HDIM, dq, 1.0f / (sk * c), h);
     m = wave_max_f32(m);
-    if (lane == 0) atomic_max_abs(amax_dq, m);
+    if (lane == 0) atomic_max_abs_seen(amax_dq, m, seen_dq);
 }
 
 // attn_bwd_kv: a wave owns 32 keys and walks over the query tiles (score tiles with queries along the rows:
@@ -1570,6 +1595,7 @@ __device__ __forceinline__ void attn_bwd_kv(const float *__restrict__ Q, const f
         }
     }
     float mk = 0.0f, mv = 0.0f;
+    const float seen_dk = amax_peek(amax_dkv), seen_dv = amax_peek(amax_dkv + AMAX_STRIDE);
     if (j < n) {
         mk = store_head_rows(dK + (tok0 + j) * D_MODEL + hd * HDIM, dk, 1.0f / (sq * c), h);
         mv = store_head_rows(dV + (tok0 + j) * D_MODEL + hd * HDIM, dv, 1.0f / (1024.0f * sg), h);
@@ -1577,8 +1603,8 @@ __device__ __forceinline__ void attn_bwd_kv(const float *__restrict__ Q, const f
     mk = wave_max_f32(mk);
     mv = wave_max_f32(mv);
     if (lane == 0) {
-        atomic_max_abs(amax_dkv, mk);
-        atomic_max_abs(amax_dkv + AMAX_STRIDE, mv);
+        atomic_max_abs_seen(amax_dkv, mk, seen_dk);
+        atomic_max_abs_seen(amax_dkv + AMAX_STRIDE, mv, seen_dv);
     }
 }
 // both halves of the attention backward in one launch: blockIdx.z = 0 computes dQ, 1 computes dK and dV
