@@ -3,11 +3,14 @@
 // model train branch CVRP/CVRPModel.py:311-345; TSP/TSPModel.py:206-217), and the same forward for
 // inference when a row has more than one 32-token tile (knn + depot_knn + 2 > 32).
 //
-// Unlike the fused decode kernels this path is a sequence of plain kernels over the flattened
-// token axis (M = R*n tokens): one strided GEMM kernel (split-binary16 MFMA, binary32 accumulation)
-// serves the three products of a linear layer (Y = X W^T, dX = dY W, dW += dY^T X), attention runs
-// per (row, head) and recomputes its probabilities in the backward pass, the output stage computes
-// the teacher's probability and the gradient of  -mean(log p_teacher)  with respect to the logits.
+// Unlike the fused decode kernels this path is a sequence of kernels over the flattened token axis (M = R*n tokens),
+// all on the f16 matrix cores with split operands and binary32 accumulation:
+//   gemm_aw_kernel    activation x packed weight (Q, K, V; the input gradient of a block)
+//   ff_fused_kernel   everything between a block's attention and the next block, forwards, in one launch
+//   ff_bwd_kernel     the same chain backwards
+//   attn_fwd_kernel, attn_bwd_kernel   attention per (row, head); probabilities recomputed in the backward pass
+//   gemm_kernel       activation x activation: the weight gradients, as partial sums per chunk of tokens
+//   output_kernel     logits, probabilities, greedy pick; the teacher's probability and d(-mean log p_teacher)/dX
 // Sums over tokens (weight and bias gradients) are formed as partial sums per chunk of tokens and
 // added in a fixed order: no float atomics, so gradients are bit-reproducible from run to run.
 #include "policy_layout.h"
@@ -783,6 +786,9 @@ struct FfArgs {
     float *O1, *amax_o1;                // [M][128] and its bound, or both NULL (not kept)
     float *H, *amax_h;                  // hidden layer [M][512] and its bound, or both NULL
     float *Y, *amax_y;
+    // the next block's Q = Y Wq, K = Y Wk, V = Y Wv in the same launch (Y is at hand), or Wqp NULL
+    const _Float16 *Wqp, *Wkp, *Wvp;    // packed, K = 128, 128 columns each
+    float *Q, *K, *V, *amax_qkv;        // [M][128] each; their three bounds, AMAX_STRIDE apart
     int M;
 };
 #define FF_LD1 (D_MODEL + 8)
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
     extern __shared__ __align__(16) _Float16 ff_lds[];
     _Float16 *X1h = ff_lds, *X1l = X1h + 32 * FF_LD1, *H2h = X1l + 32 * FF_LD1, *H2l = H2h + 32 * FF_LD2;
     float *bias = reinterpret_cast<float *>(H2l + 32 * FF_LD2);               // b1 [512], b2 [128], bc [128]
-    unsigned *wg_max = reinterpret_cast<unsigned *>(bias + FF_BIAS_FLOATS);   // largest value of: hidden half 0, 1, O1
+    unsigned *wg_max = reinterpret_cast<unsigned *>(bias + FF_BIAS_FLOATS);   // largest value of: hidden half 0, 1, O1, Y
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
     u32x4 b0[16], b1r[16];
@@ -803,6 +809,8 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
     };
     auto w1_chunk = [&](int tile) { return reinterpret_cast<const u32x4 *>(a.W1p) + (long)(tile * (D_MODEL / 16)) * 2 * 64 + lane; };
     auto w2_chunk = [&](int kc) { return reinterpret_cast<const u32x4 *>(a.W2p) + (long)(w * (FF_DIM / 16) + 8 * kc) * 2 * 64 + lane; };
+    auto qkv_chunk = [&](const _Float16 *Wp) { return reinterpret_cast<const u32x4 *>(Wp) + (long)(w * (D_MODEL / 16)) * 2 * 64 + lane; };
+    const bool qkv = a.Wqp != nullptr;
     // eight k-steps: weight fragments from registers (A operand), the tokens' image rows from LDS (B operand)
     auto steps8 = [&](const u32x4 (&b)[16], const _Float16 *Th, const _Float16 *Tl, f32x16 acc) {
 #pragma unroll
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         load16(b0, reinterpret_cast<const u32x4 *>(a.Wcp) + (long)(w * (D_MODEL / 16)) * 2 * 64 + lane);
         for (int i = tid; i < FF_BIAS_FLOATS; i += 256)
             bias[i] = i < FF_DIM ? a.b1[i] : i < FF_DIM + D_MODEL ? a.b2[i - FF_DIM] : a.bc[i - FF_DIM - D_MODEL];
-        if (tid < 3) wg_max[tid] = 0u;
+        if (tid < 4) wg_max[tid] = 0u;
         sa = pow2_scale_for(amax_read(a.amax_ao));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -948,8 +956,10 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         __syncthreads();
         f32x16 part = steps8(b1r, H2hq, H2lq, zero16());
         if (hf == 0) load16(b1r, w1_chunk(w + 8));
+        else if (qkv) load16(b1r, qkv_chunk(a.Wqp));
         part = steps8(b0, H2hq + 128, H2lq + 128, part);
         if (hf == 0) load16(b0, w1_chunk(w + 12));
+        else if (qkv) load16(b0, qkv_chunk(a.Wkp));
         const float unscale_h = 1.0f / sh;
 #pragma unroll
         for (int e = 0; e < 16; ++e) y[e] += part[e] * unscale_h;
@@ -966,6 +976,7 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
             float v = y[4 * g + m] + bv[m];
             v = resid[4 * g + m] + v;
             o[m] = v;
+            y[4 * g + m] = row_ok ? v : 0.0f;
             ymax = fmaxf(ymax, fabsf(v));
         }
         if (row_ok) *reinterpret_cast<float4 *>(Yout + (long)row * D_MODEL + cbw + 8 * g) = float4{o[0], o[1], o[2], o[3]};
@@ -976,6 +987,47 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
         if (a.amax_y) atomic_max_abs_seen(a.amax_y, ymax, seen_y);
         if (a.amax_h) atomic_max_abs_seen(a.amax_h, hmax, seen_h);
         if (a.amax_o1) atomic_max_abs_seen(a.amax_o1, o1max, seen_o1);
+    }
+    if (!qkv) return;
+    // ---- the next block's Q, K, V from Y's image (wave w: columns 32 w .. 32 w + 31 of each)
+    if (lane == 0) atomicMax(&wg_max[3], __float_as_uint(ymax));
+    __syncthreads();                           // (O1's image was last read before the hidden layer's second half was written)
+    const float sy = pow2_scale_for(__uint_as_float(wg_max[3]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned h0, l0, h1, l1;
+        split2(y[4 * g] * sy, y[4 * g + 1] * sy, h0, l0);
+        split2(y[4 * g + 2] * sy, y[4 * g + 3] * sy, h1, l1);
+        *reinterpret_cast<u32x2 *>(X1h + q * FF_LD1 + cbw + 8 * g) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(X1l + q * FF_LD1 + cbw + 8 * g) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    const float unscale_y = 1.0f / sy;
+    float *const out[3] = {a.Q, a.K, a.V};
+    float seen_p[3], pmax[3];
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) seen_p[pi] = amax_peek(a.amax_qkv + pi * AMAX_STRIDE);
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        // chunks: Wq in b1r, Wk in b0 (requested during the last product above), Wv into b1r once Wq's steps are done
+        const f32x16 acc = pi == 1 ? steps8(b0, X1hq, X1lq, zero16()) : steps8(b1r, X1hq, X1lq, zero16());
+        if (pi == 0) load16(b1r, qkv_chunk(a.Wvp));
+        float m_ = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                o[m] = acc[4 * g + m] * unscale_y;
+                m_ = fmaxf(m_, fabsf(o[m]));
+            }
+            if (row_ok) *reinterpret_cast<float4 *>(out[pi] + (long)row * D_MODEL + cbw + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+        }
+        pmax[pi] = wave_max_f32(row_ok ? m_ : 0.0f);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) atomic_max_abs_seen(a.amax_qkv + pi * AMAX_STRIDE, pmax[pi], seen_p[pi]);
     }
 }
 // The same chain backwards, one launch: dH = (dY W2) where H > 0;  dO1 = dY + dH W1;  dAO = dO1 Wc  (dY the gradient of
@@ -2032,6 +2084,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     GemmLaunch()
         .add(linear_fwd(T, nullptr, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], bound(AX_X), D_MODEL, M, D_MODEL, F, false, nullptr, 0))
         .run(s);
+    bool qkv_done = false;                             // this block's Q, K, V came out of the previous block's last launch
     for (int l = 0; l < 4; ++l) {
         const dgl_block_weights_t &k = w->block[l];
         const float *Xin = X[l], *ax_in = bound(AX_X + l);
@@ -2040,7 +2093,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             hipLaunchKernelGGL(anchor_fwd_kernel, dim3(R, n_anchor), dim3(128), 0, s, X[1], Ea, n, anchor0, anchor1,
                                w->anchor_w[0], w->anchor_b[0], w->anchor_w[cvrp ? 1 : 0], w->anchor_b[cvrp ? 1 : 0], bound(AX_X + 1));
         }
-        {   // Q, K, V: three products with the same A
+        if (!qkv_done) {   // Q, K, V: three products with the same A
             AwArgs a = aw_args(Xin, ax_in, D_MODEL, D_MODEL);
             a.p[0] = aw_product(pk[0][l][0], Qb[l], bound(AX_QKV + 3 * l), D_MODEL);
             a.p[1] = aw_product(pk[0][l][1], Kb[l], bound(AX_QKV + 3 * l + 1), D_MODEL);
@@ -2055,7 +2108,14 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             // kept only for the backward pass
             FfArgs f{AO[l], bound(AX_AO + l), Xin, pk[0][l][3], pk[0][l][4], pk[0][l][5], k.bc, k.b1, k.b2,
                      train ? O1[l] : nullptr, train ? bound(AX_O1 + l) : nullptr, train ? H[l] : nullptr,
-                     train ? bound(AX_H + l) : nullptr, X[l + 1], bound(AX_X + l + 1), M};
+                     train ? bound(AX_H + l) : nullptr, X[l + 1], bound(AX_X + l + 1),
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M};
+            // the next block's Q, K, V ride along - except into block 1, whose input has its anchors re-embedded first
+            qkv_done = l + 1 < 4 && l + 1 != 1;
+            if (qkv_done) {
+                f.Wqp = pk[0][l + 1][0]; f.Wkp = pk[0][l + 1][1]; f.Wvp = pk[0][l + 1][2];
+                f.Q = Qb[l + 1]; f.K = Kb[l + 1]; f.V = Vb[l + 1]; f.amax_qkv = bound(AX_QKV + 3 * (l + 1));
+            }
             hipLaunchKernelGGL(ff_fused_kernel, dim3((M + 31) / 32), dim3(256), FF_LDS_BYTES, s, f);
             continue;
         }
