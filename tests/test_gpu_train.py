@@ -107,7 +107,7 @@ def test_cvrp_train_step_matches_autograd(N, knn, kd, device):
     assert torch.equal(prob2, prob) and torch.equal(tr.grads, first), "gradients are not reproducible"
 
 
-@pytest.mark.parametrize("N,knn,kd", [(120, 25, 25), (260, 100, 100)])
+@pytest.mark.parametrize("N,knn,kd", [(30, 1, 1), (60, 15, 16), (120, 25, 25), (260, 100, 100), (300, 127, 127)])   # 4 ... 256 tokens
 def test_fused_chains_match_separate_launches(N, knn, kd, device, monkeypatch):
     """Everything after a block's attention runs as one launch per direction; DGL_FF_FUSED=0 and DGL_GRAD_PAIRED=1 keep
     the earlier sequences of launches.  Same products and sums up to the scaling of intermediate operands (by the
