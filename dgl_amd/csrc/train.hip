@@ -6,6 +6,7 @@
 // Unlike the fused decode kernels this path is a sequence of kernels over the flattened token axis (M = R*n tokens),
 // all on the f16 matrix cores with split operands and binary32 accumulation:
 //   gemm_aw_kernel    activation x packed weight (Q, K, V; the input gradient of a block)
+//   embed_qkv_kernel  the live tokens of the caller's tile, their embedding, the first block's Q, K, V
 //   ff_fused_kernel   everything between a block's attention and the next block, forwards, in one launch
 //   ff_bwd_kernel     the same chain backwards
 //   attn_fwd_kernel, attn_bwd_kernel   attention per (row, head); probabilities recomputed in the backward pass
@@ -1010,6 +1011,128 @@ __global__ __launch_bounds__(256, 2) void ff_fused_kernel(FfArgs a) {
 #pragma unroll
     for (int pi = 0; pi < 3; ++pi) {
         // chunks: Wq in b1r, Wk in b0 (requested during the last product above), Wv into b1r once Wq's steps are done
+        const f32x16 acc = pi == 1 ? steps8(b0, X1hq, X1lq, zero16()) : steps8(b1r, X1hq, X1lq, zero16());
+        if (pi == 0) load16(b1r, qkv_chunk(a.Wvp));
+        float m_ = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                o[m] = acc[4 * g + m] * unscale_y;
+                m_ = fmaxf(m_, fabsf(o[m]));
+            }
+            if (row_ok) *reinterpret_cast<float4 *>(out[pi] + (long)row * D_MODEL + cbw + 8 * g) = float4{o[0], o[1], o[2], o[3]};
+        }
+        pmax[pi] = wave_max_f32(row_ok ? m_ : 0.0f);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi) atomic_max_abs_seen(a.amax_qkv + pi * AMAX_STRIDE, pmax[pi], seen_p[pi]);
+    }
+}
+// The network's entry in one launch: the live tokens of the caller's tile, their embedding X0 = T We^T + be
+// (TSP/TSPModel.py:262-266, CVRP/CVRPModel.py:402-408: F <= 12 features per token, binary32 FMAs) and the first
+// block's Q, K, V from X0's image, as at the end of ff_fused_kernel.  32 tokens per workgroup; lane (q, h) of wave w
+// owns token q and features 32 w + 4 h + 8 g + {0..3}.
+struct EmbedArgs {
+    const float *tile;                  // [R][row_stride]: n tokens of DGL_TILE_STRIDE floats per row
+    int row_stride, n, F, M;
+    const float *We, *be;               // [128][F], [128]
+    float *T;                           // compact copy of the tokens [M][DGL_TILE_STRIDE] (the backward pass reads it), or NULL
+    float *X0, *amax_x0;
+    const _Float16 *Wqp, *Wkp, *Wvp;    // packed, K = 128, 128 columns each
+    float *Q, *K, *V, *amax_qkv;
+};
+#define EMBED_LDS_BYTES (2 * 32 * FF_LD1 * 2 + (32 * DGL_TILE_STRIDE + D_MODEL * DGL_TILE_STRIDE + D_MODEL) * 4 + 16)
+__global__ __launch_bounds__(256, 2) void embed_qkv_kernel(EmbedArgs a) {
+    extern __shared__ __align__(16) _Float16 ff_lds[];
+    _Float16 *X1h = ff_lds, *X1l = X1h + 32 * FF_LD1;
+    float *Tl = reinterpret_cast<float *>(X1l + 32 * FF_LD1);                 // [32][DGL_TILE_STRIDE]
+    float *Wl = Tl + 32 * DGL_TILE_STRIDE, *bl = Wl + D_MODEL * DGL_TILE_STRIDE;  // [128][F], [128]
+    unsigned *wg_max = reinterpret_cast<unsigned *>(bl + D_MODEL);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32;
+    u32x4 b0[16], b1r[16];
+    auto load16 = [&](u32x4 (&b)[16], const u32x4 *p) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b[e] = p[64 * e];
+    };
+    auto qkv_chunk = [&](const _Float16 *Wp) { return reinterpret_cast<const u32x4 *>(Wp) + (long)(w * (D_MODEL / 16)) * 2 * 64 + lane; };
+    auto steps8 = [&](const u32x4 (&b)[16], const _Float16 *Th, const _Float16 *Tlo, f32x16 acc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 th = *reinterpret_cast<const f16x8 *>(Th + 16 * t), tl = *reinterpret_cast<const f16x8 *>(Tlo + 16 * t);
+            const f16x8 bh = as_f16x8(b[2 * t]), blo = as_f16x8(b[2 * t + 1]);
+            acc = MFMA16(bh, tl, acc);
+            acc = MFMA16(blo, th, acc);
+            acc = MFMA16(bh, th, acc);
+        }
+        return acc;
+    };
+    // ---- the tokens (rows beyond M: the last token, masked below), the embedding's weights
+    for (int o = tid; o < 32 * DGL_TILE_STRIDE; o += 256) {
+        const int row = o / DGL_TILE_STRIDE, c = o % DGL_TILE_STRIDE;
+        const int m = min(i0 + row, a.M - 1), r = m / a.n, t = m % a.n;
+        const float v = a.tile[(long)r * a.row_stride + t * DGL_TILE_STRIDE + c];
+        Tl[o] = v;
+        if (a.T != nullptr && i0 + row < a.M) a.T[(long)(i0 + row) * DGL_TILE_STRIDE + c] = v;
+    }
+    load16(b1r, qkv_chunk(a.Wqp));
+    load16(b0, qkv_chunk(a.Wkp));
+    for (int o = tid; o < D_MODEL * a.F; o += 256) Wl[o] = a.We[o];
+    if (tid < D_MODEL) bl[tid] = a.be[tid];
+    if (tid == 0) wg_max[0] = 0u;
+    __syncthreads();
+    const int row = i0 + q;
+    const bool row_ok = row < a.M;
+    const int cbw = 32 * w + 4 * h;
+    float *const X0 = a.X0;
+    float y[16], tq[DGL_TILE_STRIDE];
+#pragma unroll
+    for (int f = 0; f < DGL_TILE_STRIDE; ++f) tq[f] = Tl[q * DGL_TILE_STRIDE + f];
+    float ymax = 0.0f;
+    const float seen_x = a.amax_x0 ? amax_peek(a.amax_x0) : 0.0f;
+    const int F = a.F;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = cbw + 8 * g + m;
+            float acc = 0.0f;
+#pragma unroll
+            for (int f = 0; f < DGL_TILE_STRIDE; ++f)
+                if (f < F) acc = fmaf(tq[f], Wl[c * F + f], acc);
+            const float v = row_ok ? acc + bl[c] : 0.0f;
+            y[4 * g + m] = v;
+            ymax = fmaxf(ymax, fabsf(v));
+        }
+        if (row_ok) *reinterpret_cast<float4 *>(X0 + (long)row * D_MODEL + cbw + 8 * g) = float4{y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+    }
+    ymax = wave_max_f32(ymax);
+    if (lane == 0) {
+        if (a.amax_x0) atomic_max_abs_seen(a.amax_x0, ymax, seen_x);
+        atomicMax(&wg_max[0], __float_as_uint(ymax));
+    }
+    __syncthreads();
+    const float sy = pow2_scale_for(__uint_as_float(wg_max[0]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned h0, l0, h1, l1;
+        split2(y[4 * g] * sy, y[4 * g + 1] * sy, h0, l0);
+        split2(y[4 * g + 2] * sy, y[4 * g + 3] * sy, h1, l1);
+        *reinterpret_cast<u32x2 *>(X1h + q * FF_LD1 + cbw + 8 * g) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(X1l + q * FF_LD1 + cbw + 8 * g) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    const _Float16 *X1hq = X1h + q * FF_LD1 + 8 * h, *X1lq = X1l + q * FF_LD1 + 8 * h;
+    const float unscale_y = 1.0f / sy;
+    float *const out[3] = {a.Q, a.K, a.V};
+    float seen_p[3], pmax[3];
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) seen_p[pi] = amax_peek(a.amax_qkv + pi * AMAX_STRIDE);
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
         const f32x16 acc = pi == 1 ? steps8(b0, X1hq, X1lq, zero16()) : steps8(b1r, X1hq, X1lq, zero16());
         if (pi == 0) load16(b1r, qkv_chunk(a.Wvp));
         float m_ = 0.0f;
@@ -2079,12 +2202,20 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
 
     // ---- forward
-    hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
-                       io->tile_row_stride, R, n, T);
-    GemmLaunch()
-        .add(linear_fwd(T, nullptr, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], bound(AX_X), D_MODEL, M, D_MODEL, F, false, nullptr, 0))
-        .run(s);
-    bool qkv_done = false;                             // this block's Q, K, V came out of the previous block's last launch
+    bool qkv_done = false;                             // this block's Q, K, V came out of the previous launch
+    if (ff_fused_enabled()) {
+        // the live tokens, their embedding and the first block's Q, K, V in one launch
+        EmbedArgs e{io->tile, io->tile_row_stride, n, F, M, w->emb_w, w->emb_b, train ? T : nullptr, X[0], bound(AX_X),
+                    pk[0][0][0], pk[0][0][1], pk[0][0][2], Qb[0], Kb[0], Vb[0], bound(AX_QKV)};
+        hipLaunchKernelGGL(embed_qkv_kernel, dim3((M + 31) / 32), dim3(256), EMBED_LDS_BYTES, s, e);
+        qkv_done = true;
+    } else {
+        hipLaunchKernelGGL(gather_tile_kernel, dim3(min((M * DGL_TILE_STRIDE + 255) / 256, 2048)), dim3(256), 0, s, io->tile,
+                           io->tile_row_stride, R, n, T);
+        GemmLaunch()
+            .add(linear_fwd(T, nullptr, DGL_TILE_STRIDE, w->emb_w, w->emb_b, X[0], bound(AX_X), D_MODEL, M, D_MODEL, F, false, nullptr, 0))
+            .run(s);
+    }
     for (int l = 0; l < 4; ++l) {
         const dgl_block_weights_t &k = w->block[l];
         const float *Xin = X[l], *ax_in = bound(AX_X + l);
