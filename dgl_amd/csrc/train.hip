@@ -15,6 +15,7 @@
 // Sums over tokens (weight and bias gradients) are formed as partial sums per chunk of tokens and
 // added in a fixed order: no float atomics, so gradients are bit-reproducible from run to run.
 #include "policy_layout.h"
+#define DGL_SPLIT_NO_ASM      // these kernels keep their matrix results in VGPRs: see split_f16.h
 #include "split_f16.h"
 
 #include <cstdlib>

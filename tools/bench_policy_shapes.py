@@ -3,7 +3,7 @@
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 R = sys.argv[1] if len(sys.argv) > 1 else "512"
-shapes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["12", "21", "11"]
+shapes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["12", "11"]
 for rep in range(3):
     for sh in shapes:
         env = dict(os.environ, DGL_POLICY_SHAPE=sh)
