@@ -47,6 +47,27 @@ def test_tsp_split_f16_agrees_with_f32(R, weights, device):
     assert (a[2] == b[2]).mean() >= 0.99
 
 
+@pytest.mark.parametrize("R,knn", [(600, 30), (512, 30), (64, 50)])     # the fused kernel (two shapes); rows of more than 32 tokens
+def test_forward_gives_the_same_bits_on_every_call(R, knn, device):
+    """Nothing in the forward pass depends on timing: no float atomics, and no instruction reads a register another
+    one is still writing (a build that placed hand-written assembly next to matrix instructions with results in VGPRs
+    once failed exactly this: see dgl_amd/csrc/split_f16.h).  Twenty calls, one digest."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd.weights import random_state_dict
+    eng = _tsp_engine(R, 300, knn, device, seed=3)
+    pol = PackedPolicy(random_state_dict("TSP", 5), _lib.PROBLEM_TSP, device)
+    first = None
+    for call in range(20):
+        eng.logits.zero_(); eng.prob.zero_(); eng.selected.zero_()
+        eng.forward(pol, want_logits=True, want_prob=True)
+        got = (eng.logits.clone(), eng.prob.clone(), eng.selected.clone())
+        if first is None:
+            first = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, got)), f"call {call} differs from the first"
+
+
 def test_cvrp_split_f16_agrees_with_f32(device):
     from dgl_amd import _lib
     from dgl_amd.engine import CvrpEngine, PackedPolicy
