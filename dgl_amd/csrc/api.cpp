@@ -1,6 +1,10 @@
 // Error plumbing and version of the C ABI (host only).
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include <hip/hip_runtime.h>
 
 #include "../../include/dgl_amd.h"
 
@@ -12,6 +16,31 @@ int dgl_set_error(int code, const char *fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// Raise a kernel's dynamic-LDS limit to `bytes`, once per (current device, kernel): the attribute belongs to the device's
+// copy of the kernel, and asking again before every launch is a runtime call on paths whose launches are microseconds
+// apart.  The limit only grows.
+void dgl_max_dynamic_lds(const void *kernel, int bytes) {
+    struct Seen {
+        const void *kernel;
+        int device, bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Seen &e : seen) {
+        if (e.kernel == kernel && e.device == device) {
+            if (e.bytes >= bytes) return;
+            e.bytes = bytes;
+            (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            return;
+        }
+    }
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (device >= 0) seen.push_back(Seen{kernel, device, bytes});
 }
 
 extern "C" int dgl_version(void) { return DGL_AMD_VERSION; }

@@ -348,7 +348,7 @@ extern "C" int dgl_beam_advance_compact(const dgl_policy_io_t *io, const float *
     while (P < beam * io->n && P < COMPACT_CAP) P <<= 1;       // more candidates than slots: the kernel's two-pass form
     size_t lds = (size_t)(P + beam) * sizeof(u64);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)beam_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dgl_max_dynamic_lds((const void *)beam_compact_kernel, (int)lds);
     hipLaunchKernelGGL(beam_compact_kernel, dim3(G), dim3(BEAM_THREADS), lds, (hipStream_t)stream, *io, prob, scores,
                        beam, A, step, prev_k_out, action_out, P);
     DGL_CHECK_LAUNCH("dgl_beam_advance_compact");

@@ -11,6 +11,7 @@
 
 // host-side error plumbing (api.cpp)
 int dgl_set_error(int code, const char *fmt, ...);
+void dgl_max_dynamic_lds(const void *kernel, int bytes);      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
 #define DGL_CHECK_ARG(cond, ...)                                           \
     do {                                                                   \
         if (!(cond)) return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, __VA_ARGS__); \

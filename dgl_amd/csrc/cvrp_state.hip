@@ -444,7 +444,7 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     size_t lds = (size_t)M * (st->demand_in_distance ? 3 : 2) * sizeof(float);
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset", st->N);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)cvrp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dgl_max_dynamic_lds((const void *)cvrp_reset_kernel, (int)lds);
     hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 255) / 256, st->B), dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_cvrp_reset");
     return DGL_OK;
@@ -466,15 +466,13 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
         // few rows: four (or eight) waves share a row
         if (waves == 8) {
             if (lds_split > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<8, UPDATE, D3, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<8, UPDATE, D3, true>, (int)lds_split);
             hipLaunchKernelGGL((cvrp_step_kernel<8, UPDATE, D3, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
                                *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
                                per_wave, link);
         } else {
             if (lds_split > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<4, UPDATE, D3, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<4, UPDATE, D3, true>, (int)lds_split);
             hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
                                *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
                                per_wave, link);
@@ -488,8 +486,7 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
                       depot_knn, lds1);
         if (lds1 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)cvrp_step_kernel<1, UPDATE, D3>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            dgl_max_dynamic_lds((const void *)cvrp_step_kernel<1, UPDATE, D3>, (int)lds1);
         hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
                            t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave, link);
     }

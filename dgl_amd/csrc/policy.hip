@@ -41,13 +41,15 @@ __global__ void pack_tile_kernel(const float *__restrict__ W, int IN, int ot, in
 // f16 stream: fragment pair j (K-step s0 + j) of out tile `ot`:
 //   dst[(2j*stride + part)*512 + lane*8 + e] = part(W[32*ot + (lane&31)][16(s0+j) + 8(lane>>5) + e]),
 // part 0 = hi = binary16(W), part 1 = lo = binary16(W - hi)
+// *unfit is set when a weight cannot be split (NaN, or beyond binary16's range)
 __global__ void pack_tile16_kernel(const float *__restrict__ W, int IN, int ot, int s0, int ns, _Float16 *__restrict__ dst,
-                                   int stride) {
+                                   int stride, float *__restrict__ unfit) {
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < ns * 512; o += gridDim.x * blockDim.x) {
         const int e = o & 7, lane = (o >> 3) & 63, j = o >> 9;
         const float w = W[(size_t)(32 * ot + (lane & 31)) * IN + 16 * (s0 + j) + 8 * (lane >> 5) + e];
         const _Float16 hi = (_Float16)w;
         const _Float16 lo = (_Float16)(w - (float)hi);
+        if (!(fabsf(w) < 65504.0f)) *unfit = 1.0f;
         dst[(size_t)(2 * j * stride) * 512 + lane * 8 + e] = hi;
         dst[(size_t)(2 * j * stride + 1) * 512 + lane * 8 + e] = lo;
     }
@@ -82,7 +84,7 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
     // pairs `stride` fragments apart
     auto tile16 = [&](const float *W, int IN, int ot, int s0, int ns, size_t frag, int stride) {
         hipLaunchKernelGGL(pack_tile16_kernel, dim3(4), dim3(256), 0, s, W, IN, ot, s0, ns,
-                           reinterpret_cast<_Float16 *>(packed + PK_STREAM16 + frag * FRAG), stride);
+                           reinterpret_cast<_Float16 *>(packed + PK_STREAM16 + frag * FRAG), stride, packed + PK_WEIGHTS_UNFIT);
     };
     auto vec = [&](const float *v, int n, int off) {
         hipLaunchKernelGGL(pack_copy_kernel, dim3(1), dim3(256), 0, s, v, n, packed + off);
@@ -98,6 +100,7 @@ extern "C" int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl
     for (int a = 0; a < 2; ++a) vec(w->anchor_b[w->problem == DGL_PROBLEM_CVRP ? a : 0], D_MODEL, PK_ANCHOR_B + a * D_MODEL);
     vec(w->final_w, D_MODEL, PK_FINAL_W);
     vec(w->final_b, 1, PK_FINAL_B);
+    vec(nullptr, 3, PK_FINAL_B + 1);              // PK_WEIGHTS_UNFIT and two spare words, before the tiles are packed
     for (int wv = 0; wv < 4; ++wv) {
         for (int b = 0; b < 4; ++b) {
             const dgl_block_weights_t &k = w->block[b];
@@ -459,7 +462,7 @@ static int launch_policy(const float *P, const dgl_policy_io_t *io, hipStream_t 
     const size_t lds = (size_t)(2 * ROWS * 32 * LDX + 4 * ROWS * 32) * sizeof(float);
     // (set on every launch: the attribute belongs to the current device's copy of the kernel)
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)policy_kernel_f32<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dgl_max_dynamic_lds((const void *)policy_kernel_f32<ROWS>, (int)lds);
     hipLaunchKernelGGL(policy_kernel_f32<ROWS>, dim3((io->R + ROWS - 1) / ROWS), dim3(256), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");
     return DGL_OK;

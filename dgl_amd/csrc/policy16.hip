@@ -43,7 +43,7 @@ static int launch16(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
     const size_t lds = policy16_lds_bytes<ROWS, GROUPS>();
     // (set on every launch: the attribute belongs to the current device's copy of the kernel)
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)policy_kernel_f16<ROWS, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dgl_max_dynamic_lds((const void *)policy_kernel_f16<ROWS, GROUPS>, (int)lds);
     const int per_wg = ROWS * GROUPS;
     hipLaunchKernelGGL((policy_kernel_f16<ROWS, GROUPS>), dim3((io->R + per_wg - 1) / per_wg), dim3(256 * GROUPS), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");

@@ -533,9 +533,10 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         STAMP();   // barrier
         STAMP2();
     }
-    // an operand reached the binary16 range somewhere in this row's network: tell the host (it repeats the work with
-    // the binary32 kernel); every writer stores the same value
-    if (io.overflow_out != nullptr && !(range_mx < 65504.0f)) *io.overflow_out = 1;
+    // an operand reached the binary16 range somewhere in this row's network, or a weight did when it was packed: tell
+    // the host (it repeats the work with the binary32 kernel); every writer stores the same value.  (The maxima of
+    // track_range drop NaN operands; a NaN activation stays in the residual stream and shows in the logits below.)
+    if (io.overflow_out != nullptr && (!(range_mx < 65504.0f) || headv[PK_WEIGHTS_UNFIT] != 0.0f)) *io.overflow_out = 1;
 #ifdef PROFILE_STAMPS
 #ifdef FUSED_STAMPS
     if (tid == 0 && io.prob_out)
@@ -575,6 +576,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         float logit = P[PK_FINAL_B];
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) logit += part[(ww * ROWS + rr) * 32 + q];
+        if (io.overflow_out != nullptr && q < n && logit != logit) *io.overflow_out = 1;
         policy_row_output(io, r, logit);
     }
 }

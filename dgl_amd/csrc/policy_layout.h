@@ -36,6 +36,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define PK_ANCHOR_B (PK_VEC0 + 4 * PKV_SIZE)       // [2][128]
 #define PK_FINAL_W (PK_ANCHOR_B + 2 * D_MODEL)
 #define PK_FINAL_B (PK_FINAL_W + D_MODEL)
+#define PK_WEIGHTS_UNFIT (PK_FINAL_B + 1)            // != 0: a matrix entry is NaN or beyond binary16's range (set by dgl_policy_pack)
 #define PK_STREAM0 (PK_FINAL_B + 4)
 #define FRAG 256                                    // floats (= 1 KB) per fragment
 #define BLK_FRAGS 192                               // fragments per wave per block

@@ -22,8 +22,12 @@ __device__ __attribute__((noinline)) void decode_policy_phase(const float *P, co
 }
 __device__ __attribute__((noinline)) void decode_step_phase(const dgl_tsp_state_t &st, const int32_t *selected, int t, int knn,
                                                             int32_t *idx_out, float *tile_out, int per_wave, int mom_off,
-                                                            float *step_lds, int r, int gw) {
-    tsp_step_row<2, true, true, false>(st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, TspBeamLink{}, step_lds, r, gw);
+                                                            float *step_lds, int r, int gw, bool spare) {
+    // (`spare` is uniform over a wave pair; both variants meet the same workgroup barriers)
+    if (spare)
+        tsp_step_row<2, true, true, false, true>(st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, TspBeamLink{}, step_lds, r, gw);
+    else
+        tsp_step_row<2, true, true, false>(st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, TspBeamLink{}, step_lds, r, gw);
 }
 
 __global__ __launch_bounds__(256) void tsp_decode_kernel(dgl_tsp_state_t st, const float *__restrict__ P, dgl_policy_io_t io,
@@ -32,8 +36,10 @@ __global__ __launch_bounds__(256) void tsp_decode_kernel(dgl_tsp_state_t st, con
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 1, gw = wave & 1;
-    // an odd row count leaves the last workgroup's second pair of waves without a row: they repeat the first pair's
-    // row (the same values are stored twice), so that every wave meets every barrier
+    // an odd row count leaves the last workgroup's second pair of waves without a row: they go through the first
+    // pair's row without storing anything (the step updates a row's moments in place: a second update of the same row
+    // would read values the first has already replaced), so that every wave meets every barrier
+    const bool spare = (int)blockIdx.x * 2 + grp >= st.R;
     const int r = min((int)blockIdx.x * 2 + grp, st.R - 1);
     float *step_lds = lds + (size_t)grp * step_floats;
     const int N = st.N;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void tsp_decode_kernel(dgl_tsp_state_t st, con
         const unsigned long long c2 = __builtin_amdgcn_s_memtime();
 #endif
         decode_step_phase(st, io.selected_out, t + 1, knn, const_cast<int32_t *>(io.idx_last), const_cast<float *>(io.tile),
-                          per_wave, mom_off, step_lds, r, gw);
+                          per_wave, mom_off, step_lds, r, gw, spare);
 #ifdef FUSED_STAMPS
         const unsigned long long c3 = __builtin_amdgcn_s_memtime();
 #endif
@@ -108,7 +114,7 @@ extern "C" int dgl_tsp_greedy_decode(const dgl_tsp_state_t *st, const float *pac
 #if !(defined(FUSED_STAMPS) && defined(PROFILE_STAMPS))
     k.prob_out = nullptr;
 #endif
-    (void)hipFuncSetAttribute((const void *)tsp_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dgl_max_dynamic_lds((const void *)tsp_decode_kernel, (int)lds);
     hipLaunchKernelGGL(tsp_decode_kernel, dim3((st->R + 1) / 2), dim3(256), lds, (hipStream_t)stream, *st, packed_weights, k,
                        t_done, t_end, knn, step_floats, per_wave, mom_off);
     DGL_CHECK_LAUNCH("dgl_tsp_greedy_decode");

@@ -167,8 +167,7 @@ extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, 
     if (N <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)N * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
-    hipFuncSetAttribute(reinterpret_cast<const void *>(nearest_neighbour_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<false>), (int)lds);
     hipLaunchKernelGGL(nearest_neighbour_kernel<false>, dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy,
                        (const float *)nullptr, N, solution, (int8_t *)nullptr, length);
     DGL_CHECK_LAUNCH("dgl_tsp_nearest_neighbour");
@@ -181,8 +180,7 @@ extern "C" int dgl_cvrp_nearest_neighbour(const float *xy, const float *demand, 
     if (N + 1 <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)(N + 1) * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
-    hipFuncSetAttribute(reinterpret_cast<const void *>(nearest_neighbour_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<true>), (int)lds);
     hipLaunchKernelGGL(nearest_neighbour_kernel<true>, dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy, demand,
                        N + 1, nodes, flags, (float *)nullptr);
     DGL_CHECK_LAUNCH("dgl_cvrp_nearest_neighbour");
@@ -197,8 +195,7 @@ extern "C" int dgl_cvrp_solution_augment(const int32_t *nodes, const int8_t *fla
     const int W = (N + 63) / 64;
     const size_t lds = (size_t)W * 8 + (size_t)(W + 2) * 4 + (size_t)N * 4;
     DGL_CHECK_ARG(lds <= 150 * 1024, "label too long for the workgroup's LDS");
-    hipFuncSetAttribute(reinterpret_cast<const void *>(solution_augment_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dgl_max_dynamic_lds(reinterpret_cast<const void *>(solution_augment_kernel), (int)lds);
     hipLaunchKernelGGL(solution_augment_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, nodes, flags, N, flip,
                        shift, nodes_out, flags_out);
     DGL_CHECK_LAUNCH("dgl_cvrp_solution_augment");

@@ -409,7 +409,7 @@ struct GemmLaunch {
         for (int i = 0; i < b.count; ++i) b.g[i].launch_seq = gemm_launch_seq;
         ++gemm_launch_seq;
 #endif
-        (void)hipFuncSetAttribute((const void *)gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        dgl_max_dynamic_lds((const void *)gemm_kernel, GEMM_LDS_BYTES);
         hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), GEMM_LDS_BYTES, s, b);
     }
 };
@@ -747,7 +747,7 @@ static void launch_aw(hipStream_t s, AwArgs a, int K) {
     if (K == 128) {
         hipLaunchKernelGGL(gemm_aw_kernel<128>, dim3(blocks), dim3(256), aw_lds_bytes(128, a.nseg), s, a);
     } else {
-        (void)hipFuncSetAttribute((const void *)gemm_aw_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
+        dgl_max_dynamic_lds((const void *)gemm_aw_kernel<512>, (int)aw_lds_bytes(512, 1));
         hipLaunchKernelGGL(gemm_aw_kernel<512>, dim3(blocks), dim3(256), aw_lds_bytes(512, 1), s, a);
     }
 }
@@ -761,10 +761,10 @@ static void launch_pair(hipStream_t s, GemmLaunch &gl, AwArgs a, int K) {
     a.launch_seq = gemm_launch_seq++;
 #endif
     if (K == 128) {
-        (void)hipFuncSetAttribute((const void *)gemm_pair_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(128, 3));
+        dgl_max_dynamic_lds((const void *)gemm_pair_kernel<128>, (int)aw_lds_bytes(128, 3));
         hipLaunchKernelGGL(gemm_pair_kernel<128>, dim3(gl.blocks + aw_blocks), dim3(256), lds, s, gl.b, a, gl.blocks);
     } else {
-        (void)hipFuncSetAttribute((const void *)gemm_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)aw_lds_bytes(512, 1));
+        dgl_max_dynamic_lds((const void *)gemm_pair_kernel<512>, (int)aw_lds_bytes(512, 1));
         hipLaunchKernelGGL(gemm_pair_kernel<512>, dim3(gl.blocks + aw_blocks), dim3(256), lds, s, gl.b, a, gl.blocks);
     }
 }
@@ -1343,12 +1343,18 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         if (a.amax_dao) atomic_max_abs_seen(a.amax_dao, aomax, seen_ao);
     }
 }
-// DGL_FF_FUSED=0 keeps the three products after a block's attention in separate launches (A/B runs and the test that
-// compares the two; read at every call)
-static bool ff_fused_enabled() {
+// Experiment switches, read from the environment once per call of dgl_policy_general (the test that compares the
+// variants changes them between calls):
+//   DGL_FF_FUSED=0     keeps the three products after a block's attention in separate launches
+//   DGL_GRAD_PAIRED=1  sends a block's weight-gradient batch out beside the product that writes its input gradient
+static bool g_ff_fused = true, g_grad_paired = false;
+static void read_switches() {
     const char *e = getenv("DGL_FF_FUSED");
-    return !(e && atoi(e) == 0);
+    g_ff_fused = !(e && atoi(e) == 0);
+    e = getenv("DGL_GRAD_PAIRED");
+    g_grad_paired = e && atoi(e) != 0;
 }
+static bool ff_fused_enabled() { return g_ff_fused; }
 
 // dst[e] += part[0][e] + part[1][e] + ... (in that order), e < count, rows `stride` floats apart: the ordered sum of the
 // partial products / partial column sums.  Several sums share one launch (block ranges as in gemm_kernel).
@@ -2129,6 +2135,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     if (int e = check_general(w, io, ws)) return e;
     DGL_CHECK_ARG(grad == nullptr || teacher != nullptr, "gradients need the teacher's actions");
     DGL_CHECK_ARG((reinterpret_cast<size_t>(ws) & 15) == 0, "workspace must be 16-byte aligned");
+    read_switches();
     hipStream_t s = (hipStream_t)stream;
     const int R = io->R, n = io->n, F = io->problem == DGL_PROBLEM_TSP ? 7 : 9;
     const int M = R * n;
@@ -2200,7 +2207,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
     const int NT = (n + 31) / 32;                      // attention: 32-token tiles, one wave each
     const size_t attn_fwd_lds = attn_lds_bytes(NT, 1, 1, 0), attn_q_lds = attn_lds_bytes(NT, 2, 1, 0),
                  attn_kv_lds = attn_lds_bytes(NT, 2, 2, 3 * 32 * NT + 4);
-    (void)hipFuncSetAttribute((const void *)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
+    dgl_max_dynamic_lds((const void *)attn_bwd_kernel, (int)attn_lds_bytes(8, 2, 2, 3 * 256 + 4));
 
     // ---- forward
     bool qkv_done = false;                             // this block's Q, K, V came out of the previous launch
@@ -2275,7 +2282,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
         dwf_part = ps.take((float *)grad->final_w, R, D_MODEL);
         dbf_part = ps.take((float *)grad->final_b, R, 1);
     }
-    (void)hipFuncSetAttribute((const void *)output_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (256 * (D_MODEL + 1) + 512) * (int)sizeof(float));
+    dgl_max_dynamic_lds((const void *)output_kernel, (256 * (D_MODEL + 1) + 512) * (int)sizeof(float));
     hipLaunchKernelGGL(output_kernel, dim3(R), dim3(256), ((size_t)n * (D_MODEL + 1) + n + 256) * sizeof(float), s, X[4], w->final_w, w->final_b, *io,
                        teacher, grad_scale, teacher_prob_out, train ? dA : nullptr, dwf_part, dbf_part, bound(AX_DX + 4));
     DGL_CHECK_LAUNCH("dgl_policy_general (forward)");
@@ -2324,8 +2331,7 @@ extern "C" int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_polic
             a.p[0] = aw_product(pk[1][l][0], dA3, bound(AX_DX + l), D_MODEL);
             a.p[0].Bp[1] = pk[1][l][1]; a.p[0].Bp[2] = pk[1][l][2];
             a.p[0].add = dA2; a.p[0].ldadd = D_MODEL;
-            const char *pe = getenv("DGL_GRAD_PAIRED");
-            if (pe && atoi(pe) != 0) {
+            if (g_grad_paired) {
                 launch_pair(s, gl, a, D_MODEL);
             } else {
                 gl.run(s);
@@ -2426,10 +2432,18 @@ static __device__ __align__(256) float scratch[DGL_STATIC_WORKSPACE_FLOATS];
 static float *scratch_ptr[DGL_MAX_DEVICES];          // per device, filled on the first call on that device
 static std::mutex scratch_mutex;
 
-static int static_workspace(float **out) {
+static int static_workspace(hipStream_t stream, float **out) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return dgl_set_error(DGL_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    // the array handed to the kernels is the current device's copy: a stream of another device would run them on a
+    // device whose own copy lives elsewhere
+    if (stream != nullptr) {
+        int sdev = dev;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess) return dgl_set_error(DGL_ERR_LAUNCH, "hipStreamGetDevice: %s", hipGetErrorString(e));
+        DGL_CHECK_ARG(sdev == dev, "the stream belongs to device %d, the current device is %d", sdev, dev);
+    }
     if (dev < 0 || dev >= DGL_MAX_DEVICES) return dgl_set_error(DGL_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, DGL_MAX_DEVICES);
     std::lock_guard<std::mutex> lock(scratch_mutex);
     if (scratch_ptr[dev] == nullptr) {
@@ -2455,6 +2469,6 @@ extern "C" int dgl_policy_general_static(const dgl_policy_weights_t *w, const dg
                   "(use dgl_policy_general with a caller-owned workspace)",
                   io->R, io->n, need, (size_t)DGL_STATIC_WORKSPACE_FLOATS);
     float *ws = nullptr;
-    if (int e = static_workspace(&ws)) return e;
+    if (int e = static_workspace((hipStream_t)stream, &ws)) return e;
     return dgl_policy_general(w, grad, io, teacher, grad_scale, ws, teacher_prob_out, stream);
 }

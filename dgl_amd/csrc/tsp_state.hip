@@ -104,7 +104,7 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     size_t lds = (size_t)st->N * 2 * sizeof(float);
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)tsp_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dgl_max_dynamic_lds((const void *)tsp_reset_kernel, (int)lds);
     dim3 grid((st->N + 255) / 256, st->B);
     hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_tsp_reset");
@@ -133,13 +133,11 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
     if (split && lds_split <= 150 * 1024) {
         // few rows: four waves share a row
         if (lds_split > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<4, UPDATE, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+            dgl_max_dynamic_lds((const void *)tsp_step_kernel<4, UPDATE, true>, (int)lds_split);
         static const int force_stream = getenv("DGL_STEP_STREAM") ? atoi(getenv("DGL_STEP_STREAM")) : -1;          // experiments
         if (waves == 8) {
             if (lds_split > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)tsp_step_kernel<8, UPDATE, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);
+                dgl_max_dynamic_lds((const void *)tsp_step_kernel<8, UPDATE, true>, (int)lds_split);
             hipLaunchKernelGGL((tsp_step_kernel<8, UPDATE, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
                                *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
         } else if (with_mom && lds_split <= 48 * 1024 && (force_stream >= 0 ? force_stream != 0 : (long long)st->R * st->N >= 16000000ll))
@@ -155,8 +153,7 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
         if (lds1 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)tsp_step_kernel<1, UPDATE>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            dgl_max_dynamic_lds((const void *)tsp_step_kernel<1, UPDATE>, (int)lds1);
         hipLaunchKernelGGL((tsp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
                            selected, t, knn, idx_out, tile_out, per_wave, 0, link);
     }

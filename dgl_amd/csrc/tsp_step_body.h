@@ -61,7 +61,10 @@ struct TspBeamLink {
 // in rollout.hip).  `lds`: the workgroup's step area; `wave`: this wave's index among the WAVES waves that share the
 // row (SPLIT) or among the workgroup's waves (one row per wave); SPLIT contains workgroup barriers: every wave of the
 // workgroup must call it the same number of times (the waves of all rows of a workgroup meet at them).
-template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false>
+// QUIET: the call takes part in every workgroup barrier but stores nothing to global memory (the spare wave pair of the
+// fused decode kernel's last workgroup when the row count is odd: a second in-place update of the same row would read
+// moments the first has already replaced).
+template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false, bool QUIET = false>
 __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const int32_t *__restrict__ selected, int t, int knn,
                                              int32_t *__restrict__ idx_out, float *__restrict__ tile_out, int lds_per_wave,
                                              int mom_off, const TspBeamLink &link, float *lds, int r, int wave) {
@@ -143,7 +146,8 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
                 if (UPDATE) {
                     const float dcol = dgl_sqrt_pk(dgl_chain_sq(cross, nj, cx.nc));       // dis[j][cur]
                     dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1);   // TSP/TSPEnv.py:386, 408-409
-                    if (STREAM) {
+                    if (QUIET) {
+                    } else if (STREAM) {
                         __builtin_nontemporal_store(a1, avg + j);
                         __builtin_nontemporal_store(s1, sd + j);
                     } else {
@@ -167,7 +171,8 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         }
     }
     // (a wave that still scans may read the visited word with this bit already set: it excludes `cur` anyway)
-    if (UPDATE && linked && (!SPLIT || wave == 0)) {
+    if (QUIET) {
+    } else if (UPDATE && linked && (!SPLIT || wave == 0)) {
         for (int w = lane; w < W; w += 64) vis[w] = vis_in[w] | (w == (cur >> 6) ? 1ull << (cur & 63) : 0ull);
         if (lane == 0) {
             link.hist_node[(size_t)(t - 1) * st.R + r] = cur;
@@ -201,7 +206,7 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         // others retire at once, which is what keeps saturating batches moving.
         const bool share = N >= 2048 && k <= 64;
         if (!share) {
-            if (wave != 0) return;
+            if (wave != 0 || QUIET) return;
             c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
         } else {
             const float bound = __uint_as_float(wave_candidate_bound(lane_min, k));
@@ -209,10 +214,11 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
                                         reinterpret_cast<int *>(lists + 128 * wave) + 64);
             if (lane == 0) counts[wave] = cw;
             __syncthreads();                                // `share` is uniform over the workgroup
-            if (wave != 0) return;
+            if (wave != 0 || QUIET) return;
             c = wave_candidates_from_lists(lists, counts, WAVES, keys, N, k, bound, scratch, &ckey, &cj);
         }
     } else {
+        if (QUIET) return;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);

@@ -172,10 +172,14 @@ class _TeacherProbability(torch.autograd.Function):
         (prob,) = ctx.saved_tensors
         # the kernel's gradients are those of sum_r (1/R)(-log p_r): they answer d loss / d p_r = -1 / (R p_r)
         c = grad_out.reshape(-1).double() * prob.double() * (-float(ctx.rows))
-        scale = float(c.mean())
-        if not torch.allclose(c, torch.full_like(c, scale), rtol=1e-4, atol=0.0):
+        # one reduction, one trip to the host: [mean, largest deviation from it]
+        mean = c.mean()
+        scale, spread = torch.stack((mean, (c - mean).abs().max())).tolist()
+        if not spread <= 1e-4 * abs(scale):
             raise NotImplementedError("the device backward pass differentiates -log(prob).mean() (times a constant) only")
-        out = ctx.grads if scale == 1.0 else [g * scale for g in ctx.grads]
+        # grad_out went through float32 (1/p rounded, then times p): a constant within 1e-5 of 1 IS the reference's loss,
+        # and the kernel's gradients are handed over as they are, bit-equal to PolicyTrainer.forward_backward
+        out = ctx.grads if abs(scale - 1.0) < 1e-5 else [g * scale for g in ctx.grads]
         return (None, None, None, None, *out)
 
 

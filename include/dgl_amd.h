@@ -311,7 +311,9 @@ DGL_API int dgl_policy_general(const dgl_policy_weights_t *w, const dgl_policy_w
  * tokens, 65 rows of 32); larger calls return DGL_ERR_INVALID_ARGUMENT and belong to dgl_policy_general.
  * No hipMalloc / hipFree or other allocating call is made.  The first call on a device looks the array's
  * address up (make it outside graph capture).  All calls on one device share the array: calls that overlap in
- * time on one device race.  Arguments and results otherwise exactly as dgl_policy_general. */
+ * time on one device race.  The workspace used is the current device's: `stream` must belong to the current
+ * device (anything else returns DGL_ERR_INVALID_ARGUMENT).  Arguments and results otherwise exactly as
+ * dgl_policy_general. */
 #define DGL_STATIC_WORKSPACE_FLOATS (16 * 1024 * 1024)
 DGL_API int dgl_policy_general_static(const dgl_policy_weights_t *w, const dgl_policy_weights_t *grad,
                                       const dgl_policy_io_t *io, const int32_t *teacher, float grad_scale,

@@ -148,3 +148,32 @@ def test_range_guard_reruns_in_binary32(device):
     sel = eng.selected.clone()
     ref.reset(); ref.step(start); ref.forward(PackedPolicy(big, _lib.PROBLEM_TSP, device))
     assert torch.equal(sel, ref.selected)
+
+
+def test_range_guard_sees_weights_beyond_binary16(device):
+    """A matrix entry of 1e5 saturates its binary16 image when dgl_policy_pack splits it, whatever the activations are:
+    the pack leaves a mark in the packed buffer and the split-f16 kernel reports it like an activation overflow."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy, TspEngine, forward_range_guarded
+    from oracle.dgl_oracle import random_weights
+    g = torch.Generator().manual_seed(4)
+    xy = torch.rand(6, 60, 2, generator=g).to(device)
+    start = torch.zeros(6, dtype=torch.int32, device=device)
+    w = dict(random_weights("TSP", 5))
+    m = w["decoder.layers.1.feedForward.W2.weight"].clone()
+    m[3, 17] = 1e5
+    m[9, 400] = 0.0
+    w["decoder.layers.1.feedForward.W2.weight"] = m
+    w["decoder.layers.1.feedForward.W1.bias"] = torch.full_like(w["decoder.layers.1.feedForward.W1.bias"], -1e3)  # hidden = 0
+    pol = PackedPolicy(w, _lib.PROBLEM_TSP, device)
+    eng = TspEngine(xy, 1, 30)
+    eng.reset(); eng.step(start)
+    eng.overflow.zero_()
+    eng.forward(pol)
+    assert int(eng.overflow.item()) == 1            # no activation is large (that block's hidden layer is all zeros)
+    forward_range_guarded(eng, pol)
+    sel = eng.selected.clone()
+    ref = TspEngine(xy, 1, 30)
+    ref.arithmetic = _lib.ARITH_F32
+    ref.reset(); ref.step(start); ref.forward(pol)
+    assert torch.equal(sel, ref.selected)

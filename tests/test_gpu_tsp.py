@@ -170,3 +170,28 @@ def test_fused_greedy_decode_is_bit_identical(device, monkeypatch):
     got_len = eng.greedy_rollout(pol, start).clone()
     assert torch.equal(eng.state["tour"], ref_tour) and torch.equal(got_len, ref_len)
     assert np.array_equal(ref_tour.cpu().numpy(), case["tour"][:33])
+
+
+def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch):
+    """An odd row count leaves the last workgroup of the fused decode with a spare pair of waves, which walks the last
+    row without storing anything.  Rows of 2100 nodes keep several groups of loads in flight per wave (and take the
+    shared-compaction path), so a second in-place update of the last row's moments would show as different tours."""
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from dgl_amd._lib import PROBLEM_TSP
+    _, weights = load_golden("tsp_n100_b64_nn")
+    g = torch.Generator().manual_seed(99)
+    xy = torch.rand(3, 2100, 2, generator=g).to(device)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    start = torch.tensor([5, 5, 5], dtype=torch.int32, device=device)
+    eng = TspEngine(xy, 1, 30)
+    monkeypatch.setenv("DGL_FUSED_DECODE", "0")
+    ref_len = eng.greedy_rollout(pol, start).clone()
+    ref_tour = eng.state["tour"].clone()
+    ref_avg = eng.state["avg"].clone()
+    monkeypatch.setenv("DGL_FUSED_DECODE", "1")
+    assert eng.fused_decode_available()
+    for _ in range(4):                  # the same bits on every call (the policy phase splits operands in inline assembly)
+        got_len = eng.greedy_rollout(pol, start).clone()
+        assert torch.equal(eng.state["tour"], ref_tour) and torch.equal(got_len, ref_len)
+        # NaN on the terminal step is the reference's own (division by zero unvisited nodes): compare bit patterns
+        assert torch.equal(eng.state["avg"].view(torch.int32), ref_avg.view(torch.int32))
