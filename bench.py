@@ -22,7 +22,9 @@ utilisation of the executed work.)  ``policy_f32_kernel`` times the selectable f
 kernel on the same tiles; ``roofline_knn`` the HBM-bound state-update + kNN + tile kernel, at
 the workload's batch and at a batch large enough to fill the chip; ``measured_peaks`` what this
 card delivers for a float4 triad / copy and for back-to-back matrix instructions on random
-operands.  ``cpu_baseline`` is the oracle (the PyTorch-CPU restatement of the reference path) on a
+operands; ``tsp10000_beam16`` and ``cvrp5000_train`` are BASELINE.json's configurations 4 and 5 on one GPU (a beam-16
+decode of TSP-10000 instances; a training decode step of the CVRP policy at knn = depot_knn = 100 on CVRP-5000 rows).
+``cpu_baseline`` is the oracle (the PyTorch-CPU restatement of the reference path) on a
 bounded sample.
 """
 from __future__ import annotations
@@ -339,6 +341,8 @@ def main():
                                                               "decode_steps_per_s", "mean_tour_length", "roofline",
                                                               "roofline_knn", "cpu_baseline") if k in other}
         if not args.no_aux and world == 1:
+            out["tsp10000_beam16"] = bench_tsp10000_beam(dev)
+            out["cvrp5000_train"] = bench_cvrp5000_train(dev)
             out["measured_peaks"] = mp = measured_peaks(dev)
             for o in (out, out.get(f"cvrp{args.nodes}")):
                 if o:
@@ -386,6 +390,99 @@ def knn_saturating(dev, problem: str, N: int, knn: int, rows: int = 16384):
     tile_by = tokens * 12 * 4 * rows
     return {"rows": rows, "avg_launch_ms": ms, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "bytes_per_launch": by,
             "tile_output_bytes": tile_by, "achieved_with_tile_output": (by + tile_by) / (ms * 1e-3) / 1e9}
+
+
+def bench_tsp10000_beam(dev, beam: int = 16, instances: int = 32, N: int = 10000, knn: int = 30):
+    """BASELINE.json configs[3]: TSP-10000 beam-search decode (TSP/test.py:125-129: beam 16 at this size) on the
+    device-resident beam path - per decision the policy, the expansion over beam x k candidates and one pass over the
+    state that follows the back-pointers; nothing returns to the host.  One warm-up rollout cut short, one timed."""
+    from dgl_amd._lib import PROBLEM_TSP
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from dgl_amd.weights import random_state_dict
+    g = torch.Generator().manual_seed(4)
+    R = instances * beam
+    xy = torch.rand(instances, N, 2, generator=g).to(dev)
+    eng = TspEngine(xy, beam, knn)
+    pol = PackedPolicy(random_state_dict("TSP", 789), PROBLEM_TSP, dev)
+    start = torch.full((R,), int(torch.randperm(N, generator=g)[0]), dtype=torch.int32, device=dev)
+    # the step kernel alone at this size (greedy form: state update + neighbourhood + tile for R rows of N nodes)
+    eng.reset(); eng.step(start)
+    evs = []
+    for i in range(14):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sel = torch.full((R,), 50 + i, dtype=torch.int32, device=dev)
+        a.record(); eng.step(sel); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms_step = sorted(a.elapsed_time(b) for a, b in evs[2:])
+    ms_step = sum(ms_step) / len(ms_step)
+    by = knn_bytes_per_row(N, knn, False) * R
+    eng.beam_rollout(pol, start, beam)                       # warm-up (allocates the history buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    length = eng.beam_rollout(pol, start, beam)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": f"instances/sec, TSP-{N} beam-{beam} decode", "value": instances / dt, "unit": "instances/s",
+            "rows": R, "ms_per_rollout": dt * 1e3, "us_per_decode_step": dt / (N - 1) * 1e6,
+            "best_of_beam_mean_length": float(length.view(instances, beam).min(1).values.mean()),
+            "config": {"workload": f"TSP-{N}, {instances} uniform instances x beam {beam} ({R} rows), k={knn}, "
+                                   f"random-init weights, device-resident beam path"},
+            "step_kernel": {"avg_launch_ms": ms_step, "bytes_per_launch": by, "achieved": by / (ms_step * 1e-3) / 1e9,
+                            "unit": "GB/s", "frac": by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, "rows": R, "nodes": N,
+                            "note": "greedy-form step (in-place update) timed with an event pair per launch"}}
+
+
+def bench_cvrp5000_train(dev, rows: int = 64, N: int = 5000, knn: int = 100, iters: int = 20):
+    """BASELINE.json configs[4]: one teacher-forced training decode step of the CVRP policy at the reference's training
+    neighbourhoods (CVRP/train.py:130-131: knn = depot_knn = 100, i.e. 202 tokens per row): forward in mode 'train',
+    backward, Adam (CVRP/CVRPTrainer.py:268-272), on rows of a CVRP-5000 state whose distances include the demand
+    (CVRP/CVRPEnv.py:519).  Algorithmic flops: 3 x the forward pass (backward = two products per forward product)."""
+    from dgl_amd._lib import PROBLEM_CVRP
+    from dgl_amd.engine import CvrpEngine
+    from dgl_amd.train import PolicyTrainer
+    from dgl_amd.weights import random_state_dict
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(rows, N + 1, 2, generator=g).to(dev)
+    dem = torch.cat((torch.zeros(rows, 1), torch.randint(1, 200, (rows, N), generator=g) / 500.0), 1).to(dev)
+    eng = CvrpEngine(xy, dem, 1, knn, knn, demand_in_distance=True)
+    tr = PolicyTrainer(random_state_dict("CVRP", 789), PROBLEM_CVRP, dev)
+    eng.reset()
+    eng.step(torch.full((rows,), 5 + N + 1, dtype=torch.int32, device=dev))
+    evs = []
+    for i in range(14):                                       # the step kernel with demand_in_distance at this size
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sel = torch.full((rows,), 50 + i, dtype=torch.int32, device=dev)
+        a.record(); eng.step(sel); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms_step = sorted(a.elapsed_time(b) for a, b in evs[2:])
+    ms_step = sum(ms_step) / len(ms_step)
+    by = knn_bytes_per_row(N, 2 * knn, True) * rows
+    teacher = eng.idx_last[:, 0].clone()
+
+    def one():
+        tr.zero_grad(); tr.forward_backward(eng, teacher); tr.optimizer_step()
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    n = 2 * knn + 2
+    flops = 3 * rows * policy_flops_per_row(n, 9, 2)
+    return {"metric": "ms per training decode step (forward + backward + Adam)", "value": ms, "unit": "ms",
+            "higher_is_better": False, "rows": rows, "tokens_per_row": n, "steps_timed": iters,
+            "achieved": flops / (ms * 1e-3) / 1e12, "unit_achieved": "TFLOP/s (algorithmic: 3 x forward)",
+            "frac": flops / (ms * 1e-3) / 1e12 / PEAK_F16_MATRIX_TFLOPS,
+            "config": {"workload": f"CVRP-{N} training decode step, {rows} rows x {n} tokens (knn = depot_knn = {knn}), "
+                                   f"distances over (x, y, demand), random-init weights, Adam lr 1e-4"},
+            "step_kernel": {"avg_launch_ms": ms_step, "bytes_per_launch": by, "achieved": by / (ms_step * 1e-3) / 1e9,
+                            "unit": "GB/s", "frac": by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, "rows": rows, "nodes": N + 1,
+                            "note": "demand_in_distance step, general selection (k = 100 of 5001 keys)"}}
 
 
 def cpu_baseline(problem: str, N: int, knn: int, sample: int):

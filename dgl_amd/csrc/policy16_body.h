@@ -16,6 +16,15 @@ __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x
 // Range guard: the largest operand magnitude this lane has split, as binary32 bits of a non-negative float (one
 // v_max3_f32 with |.| source modifiers per pair of values).  65504 is where the round-towards-zero conversion to
 // binary16 saturates.
+// Attention products (K Q^T and P V) as three split-operand passes like every other product (3), or as a single
+// binary16 pass with operands rounded to nearest (1): 11 significant bits per operand in a sum of 16 (scores) or 32
+// (weighted values) terms.
+#ifndef DGL_ATTN_PASSES
+#define DGL_ATTN_PASSES 3
+#endif
+#ifndef DGL_W2_PASSES
+#define DGL_W2_PASSES 3                      // 2: the second feed-forward matrix enters rounded to binary16 (experiment)
+#endif
 #ifndef DGL_RANGE_GUARD
 #define DGL_RANGE_GUARD 1
 #endif
@@ -37,6 +46,19 @@ __device__ __forceinline__ void split8(const f32x16 &x, int r0, f16x8 &hi, f16x8
     }
     hi = __builtin_bit_cast(f16x8, h);
     lo = __builtin_bit_cast(f16x8, l);
+}
+
+// registers r0..r0+7 as ONE binary16 fragment, rounded to nearest (v_cvt_pk_f16_f32): the single-pass products
+__device__ __forceinline__ f16x8 round8(const f32x16 &x, int r0, float &mx) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    u32x4 h;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x[r0 + 2 * p], x[r0 + 2 * p + 1]}, h2));
+        track_range(x[r0 + 2 * p], x[r0 + 2 * p + 1], mx);
+    }
+    return __builtin_bit_cast(f16x8, h);
 }
 
 // hi/lo images of a transposed-form tile (lane = token, register r = feature base + (r&3) + 8(r>>2)
@@ -61,7 +83,9 @@ __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float
 // acc[rr] += W(out tile) * X[rr]^T over K = 128 (8 steps of 16): transposed product, lane = token.
 // H, L: this lane's operand pointer into the hi / lo image of row 0 ([token q][8h]); rows ARRS apart.
 // BASE: position of the GEMM's first fragment in the wave's stream, modulo the ring depth.
-template <int ROWS, int ARRS, int BASE>
+// PASSES = 2 leaves the weights' low halves out (W rounded to binary16, the activation still split): an experiment
+// switch for single GEMMs (DGL_W2_PASSES), the stream is consumed the same way.
+template <int ROWS, int ARRS, int BASE, int PASSES = 3>
 __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                          f32x16 (&acc)[ROWS]) {
     // activation operands are read one K-step ahead of the MFMAs that consume them
@@ -88,7 +112,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
         __builtin_amdgcn_sched_barrier(0);      // keep the operand reads ahead of this step's MFMAs
 #pragma unroll
         for (int rr = 0; rr < ROWS; ++rr) {
-            acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+            if constexpr (PASSES == 3) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
             acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
             acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
         }
@@ -100,7 +124,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
 // 4-cycle VALU instructions written between two MFMAs cost nothing.  side(step, row, part) is called
 // after MFMA `part` (0..2) of `row` in K-step `step` and must not depend on acc; scheduling barriers
 // pin the written order.
-template <int ROWS, int ARRS, int BASE, class Side>
+template <int ROWS, int ARRS, int BASE, int PASSES = 3, class Side>
 __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                               f32x16 (&acc)[ROWS], Side side) {
     f16x8 nh[ROWS], nl[ROWS];
@@ -128,7 +152,7 @@ __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Flo
             Unroll<0, ROWS>::run([&](auto rc) {
                 constexpr int rr = decltype(rc)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (part == 0) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
+                if constexpr (part == 0 && PASSES == 3) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
                 if constexpr (part == 1) acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
                 if constexpr (part == 2) acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -248,7 +272,10 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
 
     const int anchor0 = io.k_last, anchor1 = n - 1;    // TSP: k_last == n-1
 
-    for (int layer = 0; layer < 4; ++layer) {
+#ifndef DGL_DEBUG_LAYERS
+#define DGL_DEBUG_LAYERS 4                  // debugging builds: stop after this many blocks and apply the final layer
+#endif
+    for (int layer = 0; layer < DGL_DEBUG_LAYERS; ++layer) {
         const int PV = layer * PKV_SIZE;                 // offset of this block's bias vectors in vecs
         STAMP2();  // block start
 
@@ -336,19 +363,30 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         for (int rr = 0; rr < ROWS; ++rr) {
             f32x16 o_sel = zero16();
             float pmx = 0.0f;                                // (attention weights lie in [0, 1]: their range is not tracked)
+#if DGL_ATTN_PASSES == 3
             f16x8 vh[2], vl[2];                              // V[key][feature]: keys summed, two K-steps
             split8(av[rr], 0, vh[0], vl[0], range_mx);
             split8(av[rr], 8, vh[1], vl[1], range_mx);
+#else
+            f16x8 vh[2];
+            vh[0] = round8(av[rr], 0, range_mx);
+            vh[1] = round8(av[rr], 8, range_mx);
+#endif
 #pragma unroll
             for (int hd = 0; hd < 2; ++hd) {
                 // S^T[key j][query i] = sum_d K[j][d] Q[i][d]: the 16 d of this head are one K-step
+                f32x16 s = zero16();
+#if DGL_ATTN_PASSES == 3
                 f16x8 kh, kl, qh, ql;
                 split8(ak[rr], 8 * hd, kh, kl, range_mx);
                 split8(aq[rr], 8 * hd, qh, ql, range_mx);
-                f32x16 s = zero16();
                 s = MFMA16(kl, qh, s);
                 s = MFMA16(kh, ql, s);
                 s = MFMA16(kh, qh, s);
+#else
+                const f16x8 kh = round8(ak[rr], 8 * hd, range_mx), qh = round8(aq[rr], 8 * hd, range_mx);
+                s = MFMA16(kh, qh, s);
+#endif
                 // lane (i, h) holds keys j = (m&3) + 8(m>>2) + 4h
                 // softmax over keys; 1/4 = 1/sqrt(16) is folded into the exponent:
                 //   exp((s - max)/4) = 2^((s - max) * log2(e)/4), one v_exp_f32 per key
@@ -377,11 +415,15 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
                 f32x16 o = zero16();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+#if DGL_ATTN_PASSES == 3
                     f16x8 ph, pl;
                     split8(s, 8 * t, ph, pl, pmx);
                     o = MFMA16(vl[t], ph, o);
                     o = MFMA16(vh[t], pl, o);
                     o = MFMA16(vh[t], ph, o);
+#else
+                    o = MFMA16(vh[t], round8(s, 8 * t, pmx), o);
+#endif
                 }
 #pragma unroll
                 for (int m = 0; m < 8; ++m) o_sel[8 * hd + m] = o[8 * hd + m] * inv;
@@ -425,6 +467,9 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         //   G1(0) [G1(1) || E(0)] | [G2(0) || E(1)a] [G1(2) || E(1)b] | [G2(1) || E(2)a] [G1(3) || E(2)b] |
         //   [G2(2) || E(3)] | G2(3)                                   (| = workgroup barrier)
         // The weight stream is packed in this order: W1.0 W1.1 W2.0 W1.2 W2.1 W1.3 W2.2 W2.3.
+#ifdef DGL_DEBUG_SKIP_FF
+        if (layer != DGL_DEBUG_LAYERS - 1)
+#endif
         {
             f32x16 af[ROWS], ahA[ROWS], ahB[ROWS];
 #pragma unroll
@@ -489,7 +534,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             __syncthreads();
             STAMP2();
             load_bias(1);
-            gemm16_t_with<ROWS, ROWH, 96>(ring, BH + rd, BL + rd, af, half(I0{}, ahB, CH, CL));        // G2(0) || E(1)a
+            gemm16_t_with<ROWS, ROWH, 96, DGL_W2_PASSES>(ring, BH + rd, BL + rd, af, half(I0{}, ahB, CH, CL));        // G2(0) || E(1)a
             STAMP2();
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) ahA[rr] = zero16();
@@ -498,7 +543,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             __syncthreads();
             STAMP2();
             load_bias(2);
-            gemm16_t_with<ROWS, ROWH, 128>(ring, CH + rd, CL + rd, af, half(I0{}, ahA, BH, BL));        // G2(1) || E(2)a
+            gemm16_t_with<ROWS, ROWH, 128, DGL_W2_PASSES>(ring, CH + rd, CL + rd, af, half(I0{}, ahA, BH, BL));        // G2(1) || E(2)a
             STAMP2();
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) ahB[rr] = zero16();
@@ -507,11 +552,11 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             __syncthreads();
             STAMP2();
             load_bias(3);
-            gemm16_t_with<ROWS, ROWH, 160>(ring, BH + rd, BL + rd, af, whole(ahB, CH, CL));             // G2(2) || E(3)
+            gemm16_t_with<ROWS, ROWH, 160, DGL_W2_PASSES>(ring, BH + rd, BL + rd, af, whole(ahB, CH, CL));             // G2(2) || E(3)
             STAMP2();
             __syncthreads();
             STAMP2();
-            gemm16_t<ROWS, ROWH, 176>(ring, CH + rd, CL + rd, af);                                      // G2(3)
+            gemm16_t<ROWS, ROWH, 176, DGL_W2_PASSES>(ring, CH + rd, CL + rd, af);                                      // G2(3)
             STAMP2();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

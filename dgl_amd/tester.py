@@ -79,6 +79,21 @@ class _TesterBase:
     def _start_nodes(self):
         return torch.randperm(self.env.problem_size)[:self.env.pomo_size]       # TSP/TSPTester.py:165
 
+    def _rank_batches(self, episodes, batch_size, problem_size):
+        """The batches of the whole run in its own order, each with its start draw, cut down to this rank's block of
+        instances: yields (first episode, count, start nodes).  The reference draws one set of start nodes per batch
+        (TSP/TSPTester.py:165, CVRP/CVRPTester.py:172); drawing them for every batch of the run, on every rank, and
+        never letting a rank's batch straddle two of the run's batches gives every instance the start node it gets in
+        a single process, so the reduced score does not depend on the number of ranks.  (The random angles of aug_test
+        are drawn per batch with batch-sized shapes and do depend on it.)"""
+        rank, ws = D.world()
+        lo, hi = D.shard_range(episodes, rank, ws)
+        for g0 in range(0, episodes, batch_size):
+            start = torch.randperm(problem_size)[:self.env.pomo_size]
+            a, b = max(g0, lo), min(g0 + batch_size, episodes, hi)
+            if a < b:
+                yield a, b - a, start
+
     def _summarise(self, reward, beam_size):
         """Best of the beams / multi-starts (and augmentations, TSP/TSPTester.py:183-188) of every instance."""
         if self.env_params.get("test_mode") == "aug_test":
@@ -157,27 +172,22 @@ class TSPTester(_TesterBase):
         batch_size, beam_size = tp["test_batch_size"], tp["beam_size"]
         problem_size, episodes = tp["problem_size"], tp["test_episodes"]
         self.env.load_data(tp["test_episodes_all"], problem_size)
-        rank, ws = D.world()
-        lo, hi = D.shard_range(episodes, rank, ws)
         have_base = len(self.env.baseline_len) > 0
         score_sum = gap_sum = 0.0
         count = 0
-        episode = lo
-        while episode < hi:
-            nb = min(batch_size, hi - episode)
+        for episode, nb, start in self._rank_batches(episodes, batch_size, problem_size):
             self.env.load_problems(episode, nb, problem_size, beam_size)
             self.env.start_idx, self.env.step_size = 0, nb
             if tp.get("reference_protocol"):
-                self.beamsearch_tour_nodes_shortest(beam_size, nb, problem_size)
+                self.beamsearch_tour_nodes_shortest(beam_size, nb, problem_size, start=start)
                 shortest, _ = self._summarise(self.last_lengths, beam_size)
             else:
-                shortest = self.fast_rollout(beam_size)
+                shortest = self.fast_rollout(beam_size, start=start)
             score_sum += float(shortest.double().sum())
             if have_base:
                 base = self.env.baseline_len[episode:episode + nb].to(shortest.device)
                 gap_sum += float(((shortest - base) / base).double().sum())
             count += nb
-            episode += nb
         score_sum, gap_sum, count = D.reduce_stats(score_sum, gap_sum, float(count))
         self.score = score_sum / max(count, 1.0)
         avg_gap = gap_sum / max(count, 1.0) if have_base else float("nan")
@@ -250,23 +260,18 @@ class CVRPTester(_TesterBase):
         problem_size, episodes = tp["problem_size"], tp["test_episodes"]
         self.env.problem_size = problem_size
         self.env.load_data(tp["test_episodes_all"], problem_size)
-        rank, ws = D.world()
-        lo, hi = D.shard_range(episodes, rank, ws)
         score_sum = 0.0
         count = 0
-        episode = lo
-        while episode < hi:
-            nb = min(batch_size, hi - episode)
+        for episode, nb, start in self._rank_batches(episodes, batch_size, problem_size):
             self.env.load_problems(episode, nb, problem_size)
             self.env.start_idx, self.env.step_size = 0, nb
             if tp.get("reference_protocol"):
-                self.beamsearch_tour_nodes_shortest(beam_size, nb, problem_size + 1)
+                self.beamsearch_tour_nodes_shortest(beam_size, nb, problem_size + 1, start=start)
                 shortest, _ = self._summarise(self.last_lengths, beam_size)
             else:
-                shortest = self.fast_rollout(beam_size)
+                shortest = self.fast_rollout(beam_size, start=start)
             score_sum += float(shortest.double().sum())
             count += nb
-            episode += nb
         score_sum, _, count = D.reduce_stats(score_sum, 0.0, float(count))
         self.score = score_sum / max(count, 1.0)
         self.logger.info("avg_score {:.4f}".format(self.score))

@@ -177,6 +177,16 @@ def chain_cdist(p: Tensor) -> Tensor:
     return acc.clamp_min(0).double().sqrt().float()
 
 
+def _sqrt(t: Tensor, ieee: bool) -> Tensor:
+    """torch.sqrt, or the correctly rounded square root.  On CPU, torch evaluates a contiguous float sqrt with the math
+    library it was built against (MKL's vector sqrt in its "high accuracy" mode in the container that generated the
+    golden vectors): on the AVX-512 path that is a 14-bit reciprocal-square-root estimate y refined once,
+    s = x y, s + (x - s s)(y / 2), which comes out one ulp below the correctly rounded root on 0.6 % of all inputs (every
+    time the root lies less than 0.06 ulp above the midpoint of two floats) - and other CPUs take other paths.  The
+    root in binary64 rounded to binary32 is the correctly rounded binary32 root (53 >= 2 * 24 + 2 bits)."""
+    return t.double().sqrt().float() if ieee else torch.sqrt(t)
+
+
 class TSPOracle:
     """State + policy of the TSP path.  ``w`` is a reference-format state_dict."""
 
@@ -188,7 +198,9 @@ class TSPOracle:
 
     # -- environment ------------------------------------------------------
     def reset(self, xy: Tensor, rows_per_instance: int = 1, chain: bool = False) -> None:
-        """``chain``: build the matrix with chain_cdist instead of torch.cdist (same arithmetic on every CPU)."""
+        """``chain``: the same arithmetic on every CPU - the matrix from chain_cdist instead of torch.cdist and every
+        square root correctly rounded (torch's float sqrt on CPU is the math library's, see ``_sqrt``)."""
+        self.ieee_sqrt = chain
         self.B, self.N = xy.shape[0], xy.shape[1]
         self.rpi = rows_per_instance
         self.R = self.B * rows_per_instance
@@ -216,7 +228,7 @@ class TSPOracle:
         self.d_cur = d
         avg_before = self.avg
         self.avg = (self.avg * (u + 1) - d) / u
-        self.std = torch.sqrt((torch.square(self.std) * (u + 1) - torch.square(d - avg_before)) / u)
+        self.std = _sqrt((torch.square(self.std) * (u + 1) - torch.square(d - avg_before)) / u, self.ieee_sqrt)
         if self.t == 1:
             r = torch.arange(self.R)
             start = self.xy[r, selected]
@@ -278,11 +290,11 @@ class TSPOracle:
 
 
 def tsp_rollout(oracle: TSPOracle, xy: Tensor, start: Tensor, beam: int = 1, pomo: int = 1,
-                record=None) -> Dict[str, Tensor]:
+                record=None, chain: bool = False) -> Dict[str, Tensor]:
     """Rollout loop of TSP/TSPTester.py:145-199 (test_mode 'pomo_test', no aug).
-    ``start`` holds the pomo start nodes ([pomo] int64)."""
+    ``start`` holds the pomo start nodes ([pomo] int64); ``chain``: see TSPOracle.reset."""
     B, N = xy.shape[0], xy.shape[1]
-    oracle.reset(xy, rows_per_instance=pomo * beam)
+    oracle.reset(xy, rows_per_instance=pomo * beam, chain=chain)
     G = B * pomo
     scores = torch.zeros(G, beam)
     step = 0
@@ -323,9 +335,10 @@ class CVRPOracle:
     def reset(self, depot_xy: Tensor, node_xy: Tensor, demand: Tensor, rows_per_instance: int = 1,
               train: bool = False, chain: bool = False) -> None:
         """depot_xy [B,2]; node_xy [B,N,2]; demand [B,N] (already / capacity).  ``train``: the distance
-        matrix of reset('train') (CVRP/CVRPEnv.py:519), cdist over (x, y, demand).  ``chain``: build the matrix
-        with chain_cdist instead of torch.cdist (same arithmetic on every CPU)."""
+        matrix of reset('train') (CVRP/CVRPEnv.py:519), cdist over (x, y, demand).  ``chain``: the same arithmetic on
+        every CPU (chain_cdist instead of torch.cdist, correctly rounded square roots: see TSPOracle.reset)."""
         B, N = node_xy.shape[0], node_xy.shape[1]
+        self.ieee_sqrt = chain
         self.B, self.N, self.rpi = B, N, rows_per_instance
         self.R = B * rows_per_instance
         xy = torch.cat((depot_xy[:, None, :], node_xy), dim=1)
@@ -373,7 +386,7 @@ class CVRPOracle:
         self.avg = (self.avg * (u + 1) - d) / u
         item = (torch.square(self.std) * (u + 1) - torch.square(d - avg_before)) / u
         item[item < 0] = 0
-        self.std = torch.sqrt(item)
+        self.std = _sqrt(item, self.ieee_sqrt)
         if self.t == 1:
             dep = self.xy[:, 0, :]
             dy = dep[:, 1].unsqueeze(-1).repeat(1, N + 1) - self.xy[:, :, 1]
@@ -466,11 +479,11 @@ class CVRPOracle:
 
 
 def cvrp_rollout(oracle: CVRPOracle, depot_xy: Tensor, node_xy: Tensor, demand: Tensor, start: Tensor,
-                 beam: int = 1, pomo: int = 1, record=None) -> Dict[str, Tensor]:
+                 beam: int = 1, pomo: int = 1, record=None, chain: bool = False) -> Dict[str, Tensor]:
     """Rollout loop of CVRP/CVRPTester.py:147-227 ('pomo_test').  ``start`` holds the
-    pomo start customers as 0-based indices r; the first action is r + 2 + N."""
+    pomo start customers as 0-based indices r; the first action is r + 2 + N.  ``chain``: see TSPOracle.reset."""
     B, N = node_xy.shape[0], node_xy.shape[1]
-    oracle.reset(depot_xy, node_xy, demand, rows_per_instance=pomo * beam)
+    oracle.reset(depot_xy, node_xy, demand, rows_per_instance=pomo * beam, chain=chain)
     G = B * pomo
     A = 2 * (N + 1)
     scores = torch.zeros(G, beam)

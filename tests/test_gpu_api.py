@@ -188,3 +188,57 @@ def test_reference_training_loop_on_the_swapped_in_model(device, monkeypatch):
           f"difference {rel.max():.2e}, median {np.median(rel):.2e}")
     np.testing.assert_allclose(np.array(losses), g["loss"], rtol=2e-3, atol=2e-4)
     assert np.median(rel) < 1e-4 and rel.max() < 2e-2
+
+
+def test_reference_tsp_training_loop_on_the_swapped_in_model(device, monkeypatch):
+    """The TSP counterpart: the reference's _train_one_batch loop (TSP/TSPTrainer.py:216-256), statement for statement,
+    on this build's TSPEnv / TSPModel with a torch optimizer - model(state, selected_node_list, solution, knn, step) in
+    mode 'train' returns (teacher, prob, 1) and loss.backward() fills the parameters' .grad.  Labels, augmented
+    coordinates and the teacher probabilities of every step come from one training batch of the reference's
+    self-improvement loop (selfimp_tsp_n40_b6.npz, started from the checkpoint fixture)."""
+    from conftest import GOLDEN
+    from dgl_amd import tsp as T
+    from dgl_amd.weights import load_checkpoint
+    g = np.load(os.path.join(GOLDEN, "selfimp_tsp_n40_b6.npz"))
+    knn = int(g["meta/knn"])
+    monkeypatch.setattr(T, "mix_augment", lambda xy: xy)            # the golden holds the augmented coordinates
+    env = T.TSPEnv(mode="train", pomo_size=1, append_information=TSP_INFO, knn=knn, device=str(device))
+    B, N = g["train/aug_xy"].shape[:2]
+    env.batch_size, env.problem_size = B, N
+    env.problems = torch.from_numpy(g["train/aug_xy"])
+    last_chunk = max(int(k.split("/")[0][5:]) for k in g.files if k.startswith("chunk"))
+    env.solution = torch.from_numpy(g[f"chunk{last_chunk}/aug_solution"]).to(device)
+    model = T.TSPModel(**dict(MODEL_PARAMS, mode="train", append_information=TSP_INFO)).to(device)
+    model.load_state_dict(load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt")))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)      # TSP/train.py: the same settings
+
+    model.train()
+    env.reset("train")
+    prob_list = torch.ones(size=(B, 0), device=device)
+    state, reward, done = env.pre_step()
+    model.mode = "train"
+    model.pre_forward(env.dis_matrix, env.batch_size)
+    current_step = 0
+    while not done:
+        if current_step == 0:
+            selected = env.solution[:, 0]
+            prob = torch.ones(env.solution.shape[0], 1, device=device)
+        else:
+            selected, prob, probs = model(state, env.selected_node_list, env.solution, knn, current_step)
+            loss_mean = -prob.type(torch.float64).log().mean()
+            model.zero_grad()
+            loss_mean.backward()
+            optimizer.step()
+        current_step += 1
+        state, reward, done = env.step(selected)
+        prob_list = torch.cat((prob_list, prob.detach()), dim=1)
+    assert model.decoder.k_1.weight.grad is None and model.decoder.embedding_last_node_pos.weight.grad is None
+    assert model.encoder.embedding.weight.grad is not None
+    probs = prob_list[:, 1:].t().cpu().numpy()
+    rel = np.abs(probs - g["train/prob"]) / g["train/prob"]
+    likely = g["train/prob"] >= 1e-3
+    print(f"reference TSP loop on the swapped-in model: {probs.shape[0]} Adam steps, teacher probabilities max relative "
+          f"difference {rel.max():.2e} (likely tokens {rel[likely].max():.2e}), median {np.median(rel):.2e}; "
+          f"first 12 steps {rel[:12].max():.2e}")
+    # the bounds of tests/test_gpu_selfimprove.py::_check_training (the same batch through PolicyTrainer; observed 4e-2)
+    assert np.median(rel) < 1e-4 and rel[:12].max() < 1e-3 and rel[likely].max() < 0.1 and rel.max() < 0.15

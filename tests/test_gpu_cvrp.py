@@ -201,8 +201,17 @@ def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
 @pytest.mark.parametrize("name,min_identical", [("cvrp_n100_b64_nn", 0.9), ("cvrp_n1000_b4_nn", 0.5),
                                                 ("cvrp_n100_b256_nn_tours", 0.99),
                                                 ("cvrp_n1000_b128_nn_tours", 0.99),
+                                                ("cvrp_n1000_b512_nn_tours", 0.97),
                                                 ("cvrp_n1000_b128_clustered_nn_tours", 0.8)])
 def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
+    """Greedy routes against the reference's own, trained checkpoint.  The 512-instance population of the headline
+    size is held to 97 % against the reference's run and to 99 % against the second opinion its fixture carries
+    (oracle/make_ieee_tours.py: the reference's algorithm with correctly rounded square roots and a stable argsort):
+    the reference's own run shares only 503 of 512 routes with that second run - its torch build's float sqrt is one
+    ulp low on 0.6 % of inputs, the running standard deviations amplify last bits by N / #unvisited and the min-max
+    normalisation by another hundredfold, and 32 of the 512 trajectories pass an exact distance tie at the edge of a
+    neighbourhood, which its unstable argsort resolves its own way - so 98 % is what an implementation with IEEE
+    square roots can share with it (tools/dbg_mismatch*.py locate every differing decision)."""
     from dgl_amd._lib import PROBLEM_CVRP
     from dgl_amd.engine import PackedPolicy
     case, weights = load_golden(name)
@@ -221,3 +230,36 @@ def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device)
     assert frac >= min_identical
     assert rel < 1e-4
     np.testing.assert_allclose(length[same], case["length"][same], rtol=3e-6)
+    if "ieee/nodes" in case:
+        from test_gpu_tsp import _second_opinion
+        got = nodes.astype(np.int32) + (eng.N + 1) * flags.astype(np.int32)
+        ieee = case["ieee/nodes"].astype(np.int32) + (eng.N + 1) * case["ieee/flags"].astype(np.int32)
+        ref = case["nodes"].astype(np.int32) + (eng.N + 1) * case["flags"].astype(np.int32)
+        _second_opinion(name, got, ieee, ref, case["ref_tie"])
+
+
+@pytest.mark.parametrize("name", ["cvrp_n1000_b128_nn_tours", "cvrp_n1000_b128_clustered_nn_tours"])
+def test_route_mismatches_attributed_to_reset_moments(name, device):
+    """The CVRP counterpart of test_tour_mismatches_attributed_to_reset_moments (tests/test_gpu_tsp.py): the population
+    decoded from the device's own reset and from the reference's captured reset moments; identical routes for both."""
+    from dgl_amd._lib import PROBLEM_CVRP
+    from dgl_amd.engine import PackedPolicy
+    case, weights = load_golden(name)
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_CVRP, device)
+    start = torch.from_numpy(case["start"]).to(device=device, dtype=torch.int32).repeat(eng.B) + 2 + eng.N
+    same = {}
+    for moments in ("own", "reference"):
+        eng.reset()
+        if moments == "reference":
+            eng.state["avg"].copy_(torch.from_numpy(case["avg0"]).to(device))
+            eng.state["sd"].copy_(torch.from_numpy(case["std0"]).to(device))
+        eng.step(start)
+        while eng.t < eng.N:
+            eng.forward(pol, want_logits=False, want_prob=False)
+            eng.step(eng.selected)
+        nodes, flags = eng.state["nodes"].cpu().numpy(), eng.state["flags"].cpu().numpy()
+        same[moments] = int(((nodes == case["nodes"]).all(axis=1) & (flags == case["flags"]).all(axis=1)).sum())
+    print(f"{name}: identical routes {same['own']}/{eng.R} from the device's reset, {same['reference']}/{eng.R} from the "
+          f"reference's reset moments")
+    assert same["reference"] >= same["own"] - 2

@@ -123,6 +123,7 @@ def test_greedy_rollout_length(name, device):
 @pytest.mark.parametrize("name,min_identical", [("tsp_n100_b64_nn", 0.95), ("tsp_n1000_b8_nn", 0.75),
                                                 ("tsp_n100_b512_nn_tours", 0.99),
                                                 ("tsp_n1000_b128_nn_tours", 0.99),
+                                                ("tsp_n1000_b512_nn_tours", 0.99),
                                                 ("tsp_n1000_b128_clustered_nn_tours", 0.9)])
 def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     """With the trained checkpoint fixture (peaked action distributions) the greedy tours must be
@@ -149,6 +150,25 @@ def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     assert frac >= min_identical
     assert rel < 1e-4
     np.testing.assert_allclose(length[same], case["length"][same], rtol=2e-6)
+    if "ieee/tour" in case:
+        _second_opinion(name, tour, case["ieee/tour"], case["tour"], case["ref_tie"])
+
+
+def _second_opinion(name, got, ieee, ref, tie):
+    """Fixtures that carry the second opinion of oracle/make_ieee_tours.py: the reference's algorithm with its two
+    library-dependent choices fixed the way the kernels fix them (correctly rounded square roots instead of the math
+    library's, lowest index first among equal distances).  That run is what the device must reproduce; how far the
+    reference's own run is from it (its torch build's sqrt is one ulp low on 0.6 % of inputs, and the last decisions
+    of a tour hang on the last bits of the running standard deviations) bounds what any implementation can share with
+    the reference's tours."""
+    same_ieee = (got == ieee).all(axis=1)
+    same_ref = (got == ref).all(axis=1)
+    ref_vs_ieee = (ref == ieee).all(axis=1)
+    print(f"{name}: identical to the correctly-rounded-sqrt run of the reference's algorithm {int(same_ieee.sum())}/{len(same_ieee)}"
+          f" ({100 * same_ieee.mean():.2f} %); the reference's own run shares {int(ref_vs_ieee.sum())}/{len(tie)} with that run; "
+          f"{int(tie.sum())} instances pass a neighbourhood tie on the reference's trajectory, without them the device "
+          f"shares {int((same_ref & ~tie).sum())}/{int((~tie).sum())} with the reference")
+    assert same_ieee.mean() >= 0.99
 
 
 def test_fused_greedy_decode_is_bit_identical(device, monkeypatch):
@@ -195,3 +215,33 @@ def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch):
         assert torch.equal(eng.state["tour"], ref_tour) and torch.equal(got_len, ref_len)
         # NaN on the terminal step is the reference's own (division by zero unvisited nodes): compare bit patterns
         assert torch.equal(eng.state["avg"].view(torch.int32), ref_avg.view(torch.int32))
+
+
+@pytest.mark.parametrize("name", ["tsp_n1000_b128_nn_tours", "tsp_n1000_b128_clustered_nn_tours"])
+def test_tour_mismatches_attributed_to_reset_moments(name, device):
+    """Where do the tours that differ from the reference's come from?  The device's reset sums its distances in
+    binary64 and rounds once; torch.mean / torch.std round along a float cascade, so the two sets of starting moments
+    differ in the last bit here and there, and the recurrences and the min-max normalisation carry that into the
+    logits.  This decodes the population twice - from the device's own reset, and with the reference's captured reset
+    moments (avg0 / std0 of the golden file) written over the device's - and reports identical tours for both.  What is
+    still different in the second decode is owed to the arithmetic after the reset (policy sums, square roots)."""
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd._lib import PROBLEM_TSP
+    case, weights = load_golden(name)
+    eng = _engine(case, device)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    start = torch.from_numpy(case["start"]).to(device=device, dtype=torch.int32).repeat(eng.B)
+    same = {}
+    for moments in ("own", "reference"):
+        eng.reset()
+        if moments == "reference":
+            eng.state["avg"].copy_(torch.from_numpy(case["avg0"]).to(device))
+            eng.state["sd"].copy_(torch.from_numpy(case["std0"]).to(device))
+        eng.step(start)
+        while eng.t < eng.N:
+            eng.forward(pol, want_logits=False, want_prob=False)
+            eng.step(eng.selected)
+        same[moments] = int((eng.state["tour"].cpu().numpy() == case["tour"]).all(axis=1).sum())
+    print(f"{name}: identical tours {same['own']}/{eng.R} from the device's reset, {same['reference']}/{eng.R} from the "
+          f"reference's reset moments")
+    assert same["reference"] >= same["own"] - 2
