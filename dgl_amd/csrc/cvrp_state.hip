@@ -240,6 +240,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
     const float *lists = nullptr;
     const int *counts = nullptr;
     float boundL = 0.0f, boundD = 0.0f;
+    const float *wide_min = nullptr;
+    float *wide_list = nullptr;
     if (SPLIT) {
         if (!share && wave >= 2) return;
         // LDS behind the row's arrays: scratch of wave 0 [128] | lane minima [2][64 WAVES] | scratch of wave 1 [128]
@@ -265,6 +267,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
             lists = lw + 128 * WAVES * wave;
             counts = cw + WAVES * wave;
         }
+        // the wide selection (more than 64 neighbours): this group's class minima and its half of the list area
+        wide_min = mins + WAVES * 64 * wave;
+        wide_list = scratch + 256 + 2 * WAVES * 64 + 128 * WAVES * wave;
         if (wave == 1) scratch += 128 + 2 * WAVES * 64;        // a search scratch of its own
     } else {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -307,6 +312,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         }
         if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     } else {
+        auto emit_last = [&](int j, int rank) {
+            il[rank] = j;
+            float *f = tileL + rank * DGL_TILE_STRIDE;
+            cvrp_features<D3>(st, cx, j, f);
+            finish_last(f, rank);
+        };
+        if (!(SPLIT && kl > 64 && kl <= 256 && wave_select_wide<WAVES>(keysL, M, kl, wide_min, wide_list, emit_last)))
         wave_select_general(keysL, M, kl, scratch, [&](int j, int rank) {
             il[rank] = j;
             float *f = tileL + rank * DGL_TILE_STRIDE;
@@ -339,6 +351,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         }
         if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     } else {
+        auto emit_depot = [&](int j, int rank) {
+            id[rank] = j;
+            float *f = tileD + rank * DGL_TILE_STRIDE;
+            f[3] = cvrp_features<D3>(st, cx, j, f);
+        };
+        if (!(SPLIT && kd > 64 && kd <= 256 && wave_select_wide<WAVES>(keysD, M, kd, wide_min, wide_list, emit_depot)))
         wave_select_general(keysD, M, kd, scratch, [&](int j, int rank) {
             id[rank] = j;
             float *f = tileD + rank * DGL_TILE_STRIDE;

@@ -101,9 +101,10 @@ __device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k) 
     return hi;
 }
 
-// keys[j] <= bound for j in [j_lo, j_hi) (j_lo a multiple of 64), compacted in index order: the first 64 go to
-// out_key / out_j; returns how many there are (possibly more than 64)
-__device__ __forceinline__ int wave_compact(const float *keys, int j_lo, int j_hi, float bound, float *out_key, int *out_j) {
+// keys[j] <= bound for j in [j_lo, j_hi) (j_lo a multiple of 64), compacted in index order: the first `cap` go to
+// out_key / out_j; returns how many there are (possibly more than cap)
+__device__ __forceinline__ int wave_compact(const float *keys, int j_lo, int j_hi, float bound, float *out_key, int *out_j,
+                                            int cap = 64) {
     const int lane = threadIdx.x & 63;
     int c = 0;
     for (int j0 = j_lo; j0 < j_hi; j0 += 256) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ int wave_compact(const float *keys, int j_lo, int j_h
             const bool p = key[q] <= bound;
             const unsigned long long m = __ballot(p);
             const int pos = c + lane_rank(m);
-            if (p && pos < 64) {
+            if (p && pos < cap) {
                 out_key[pos] = key[q];
                 out_j[pos] = j0 + 64 * q + lane;
             }
@@ -213,6 +214,101 @@ __device__ __forceinline__ bool wave_pick_k(float root, int c, int k, int *rank_
     }
     *rank_out = lane_rank(__ballot(pick));
     return pick;
+}
+
+// Wide neighbourhoods, 64 < k <= 256 (the reference trains with knn = depot_knn = 100, CVRP/train.py:130-131), for rows
+// scanned by W waves that left the minima of their 64 W scan classes (class = (wave, lane) of the scanning thread) in
+// LDS, class_min[64 w + lane].  Every class minimum is one of the row's keys, so the k-th smallest of them bounds the
+// row's k-th smallest key from above, and about -C ln(1 - k/C) keys lie under it (C = 64 W: 111 for k = 100, C = 512).
+// The keys under the bound (raised by 4 ulps, see wave_candidates) are compacted in index order into `list` (512 words:
+// 256 keys, 256 indices), four per lane (slot 64 q + lane); their roots are ranked as in wave_pick_k.  emit(j, rank) is
+// called for the k picks, rank ascending with the node index.  Returns false - nothing emitted - when the class minima
+// cannot bound k keys or more than 256 keys lie under the bound: the caller then takes the general path.
+template <int W, class Emit>
+__device__ __forceinline__ bool wave_select_wide(const float *keys, int n, int k, const float *class_min, float *list,
+                                                 Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const unsigned FMAX = 0x7F7FFFFFu;
+    float m[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) m[w] = class_min[64 * w + lane];
+    auto classes_le = [&](unsigned x) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) c += wave_count_le(m[w], x);
+        return c;
+    };
+    if (classes_le(FMAX) < k) return false;
+    unsigned hi = FMAX, lo = 0;
+    if (classes_le(0u) >= k) hi = 0;
+    while (hi - lo > 1) {                   // invariant: count(lo) < k <= count(hi)
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        const int cnt = classes_le(mid);
+        if (cnt >= k) {
+            hi = mid;
+            if (cnt <= k + 4) break;
+        } else {
+            lo = mid;
+        }
+    }
+    const float bound = __uint_as_float(min(hi + 4u, FMAX));
+    int *list_j = reinterpret_cast<int *>(list) + 256;
+    const int c = wave_compact(keys, 0, n, bound, list, list_j, 256);
+    if (c > 256) return false;
+    wave_lds_sync();
+    float root[4];
+    int cj[4];
+    bool pick[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = 64 * q + lane;
+        root[q] = s < c ? dgl_sqrt(list[s]) : INFINITY;
+        cj[q] = s < c ? list_j[s] : 0;
+        pick[q] = s < c;
+    }
+    if (c > k) {
+        auto roots_le = [&](unsigned x) {
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cnt += wave_count_le(root[q], x);
+            return cnt;
+        };
+        unsigned thi = FMAX, tlo = 0;                                       // count(thi) = c > k
+        bool split = false;                                                 // a probe with exactly k roots at or below it
+        if (roots_le(0u) >= k) thi = 0;
+        while (thi - tlo > 1) {                                             // invariant: count(tlo) < k <= count(thi)
+            const unsigned mid = tlo + ((thi - tlo) >> 1);
+            const int cnt = roots_le(mid);
+            if (cnt >= k) thi = mid; else tlo = mid;
+            if (cnt == k) { split = true; break; }
+        }
+        const float T = __uint_as_float(thi);
+        if (split) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pick[q] = root[q] <= T;
+        } else {                                                            // T = the k-th smallest root, tied
+            int less = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) less += __popcll(__ballot(root[q] < T));
+            const int need_eq = k - less;
+            int eq_run = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                   // slot order = index order
+                const bool eq = root[q] == T;
+                const unsigned long long meq = __ballot(eq);
+                pick[q] = root[q] < T || (eq && eq_run + lane_rank(meq) < need_eq);
+                eq_run += __popcll(meq);
+            }
+        }
+    }
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long mp = __ballot(pick[q]);
+        if (pick[q]) emit(cj[q], run + lane_rank(mp));
+        run += __popcll(mp);
+    }
+    return true;
 }
 
 // General path: all keys are rooted in place, then bisection over all keys + the two ballot scans

@@ -223,7 +223,18 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         __builtin_amdgcn_wave_barrier();
         c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
     }
-    if (c >= 0) {
+    // more than 64 neighbours, row shared by the workgroup's waves: one pass with a bound from the scan classes' minima
+    bool wide = false;
+    if (SPLIT && c < 0 && k > 64 && k <= 256) {
+        float *mins = scratch + 128;
+        wide = wave_select_wide<WAVES>(keys, N, k, mins, mins + 64 * WAVES, [&](int j, int rank) {
+            idx_row[rank] = j;
+            tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+        });
+        if (wide && lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+    }
+    if (wide) {
+    } else if (c >= 0) {
         // The inputs of every candidate's feature row (and of the anchor token = the current node, on
         // lane 63 when that lane holds no candidate) are requested before the ranking bisection.
         const bool anchor_early = (c < 64) && (lane == 63);

@@ -4,8 +4,10 @@ TSP/TSPEnv.py:119-121,222-224), greedy decode with the trained fixture checkpoin
 ORIGINAL coordinates (TSP/TSPEnv.py:508-509) and the best-of-augmentation reduction
 (TSP/TSPTester.py:183-188).  Writes tests/golden/aug_tsp_n50_b3_a4.npz, and the same for CVRPEnv
 (CVRP/CVRPEnv.py:250-257,462-467,864-865; CVRP/CVRPTester.py:197-199) as aug_cvrp_n40_b3_a4.npz.
+--published-scale: one instance of 1000 nodes with the replica counts the reference evaluates that size with
+(aug_tsp_n1000_b1_a32.npz, aug_cvrp_n1000_b1_a8.npz).
 
-usage: python oracle/make_aug_goldens.py
+usage: python oracle/make_aug_goldens.py [--published-scale]
 """
 from __future__ import annotations
 
@@ -20,10 +22,9 @@ from make_goldens import CVRP_INFO, TSP_INFO, _import_reference, model_params  #
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
-def main():
+def main(B=3, N=50, aug=4, knn=30, name="aug_tsp_n50_b3_a4"):
     import torch
     TSPModel, TSPEnv, _, _, Beamsearch = _import_reference()
-    B, N, aug, knn = 3, 50, 4, 30
     ck = torch.load(os.path.join(GOLD, "ckpt_tsp_nn.pt"), map_location="cpu", weights_only=True)
     model = TSPModel(**model_params(TSP_INFO))
     model.load_state_dict(ck["model_state_dict"])
@@ -58,7 +59,7 @@ def main():
             state, reward, done = env.step(sel)
         view = reward.view(env.batch_size // env.aug_size, env.aug_size)
         shortest, index = torch.min(view, dim=1)
-    out = os.path.join(GOLD, "aug_tsp_n50_b3_a4.npz")
+    out = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(out, xy=xy.numpy(), aug_xy=aug_xy, tour=env.selected_node_list.numpy().astype(np.int32),
                         reward=reward.numpy(), shortest=shortest.numpy(), index=index.numpy(), start=start.numpy(),
                         **{"meta/knn": np.int64(knn), "meta/aug": np.int64(aug), "meta/seed": np.int64(777),
@@ -66,10 +67,9 @@ def main():
     print("saved", out, "shortest", shortest.numpy(), "index", index.numpy())
 
 
-def main_cvrp():
+def main_cvrp(B=3, N=40, aug=4, knn=15, kd=15, name="aug_cvrp_n40_b3_a4"):
     import torch
     _, _, CVRPModel, CVRPEnv, Beamsearch = _import_reference()
-    B, N, aug, knn, kd = 3, 40, 4, 15, 15
     ck = torch.load(os.path.join(GOLD, "ckpt_cvrp_nn.pt"), map_location="cpu", weights_only=True)
     model = CVRPModel(**model_params(CVRP_INFO))
     model.load_state_dict(ck["model_state_dict"])
@@ -108,7 +108,7 @@ def main_cvrp():
             state, reward, done = env.step(sel.clone())
         view = reward.view(env.batch_size // env.aug_size, env.aug_size)
         shortest, index = torch.min(view, dim=1)
-    out = os.path.join(GOLD, "aug_cvrp_n40_b3_a4.npz")
+    out = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(out, depot_xy=depot_xy.numpy(), node_xy=node_xy.numpy(), demand=demand.numpy(), aug_xy=aug_xy,
                         nodes=env.selected_node_list.numpy().astype(np.int32),
                         flags=env.step_state.selected_flag.numpy().astype(np.int8),
@@ -119,5 +119,10 @@ def main_cvrp():
 
 
 if __name__ == "__main__":
-    main()
-    main_cvrp()
+    if "--published-scale" in sys.argv:
+        # the augmentation widths the reference evaluates N = 1000 with (TSP/test.py:126: 32 replicas; CVRP: 8)
+        main(B=1, N=1000, aug=32, name="aug_tsp_n1000_b1_a32")
+        main_cvrp(B=1, N=1000, aug=8, name="aug_cvrp_n1000_b1_a8")
+    else:
+        main()
+        main_cvrp()

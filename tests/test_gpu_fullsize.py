@@ -220,7 +220,9 @@ def test_config5_cvrp5000_training_step_at_size(device):
         d = (sd[k].cpu() - p.detach()).abs()
         # The first update is lr * g / (|g| + eps), eps = 1e-8: entries whose gradient is of eps' size or rounding
         # noise move by anything up to lr in either implementation; the others must agree closely.
-        solid = grads_ref[k].abs() >= 1e-6
+        # (d/dg of g / (|g| + eps) is eps / (|g| + eps)^2: 1e4 at |g| = 1e-6, where a gradient error of 1e-7 - the
+        # matrix products' rounding - already moves the step by 1e-3 of lr; 1e2 at |g| = 1e-5)
+        solid = grads_ref[k].abs() >= 1e-5
         assert float(d.max()) <= 2.02e-4, (k, float(d.max()))             # +lr in one, -lr in the other at worst
         if solid.any():
             assert float(d[solid].max()) < 2e-7, (k, float(d[solid].max()))

@@ -111,6 +111,33 @@ def test_more_than_64_candidates(device, N):
     _run_case(device, xy, order, 30, check_until=25)
 
 
+@pytest.mark.parametrize("N,knn,until", [(1000, 100, 30), (1000, 200, 12), (1000, 256, 8), (2500, 65, 10), (5000, 100, 16)])
+def test_wide_neighbourhoods_on_shared_rows(device, N, knn, until):
+    """More than 64 neighbours on rows that several waves share (four waves; eight from 4096 nodes on): one compaction
+    pass under a bound taken from the minima of the 256 / 512 scan classes (the reference trains with knn = 100,
+    CVRP/train.py:130-131)."""
+    rng = np.random.default_rng(N + knn)
+    xy = rng.random((2, N, 2), dtype=np.float32)
+    order = np.stack([rng.permutation(N) for _ in range(2)])
+    _run_case(device, xy, order, knn, check_until=until)
+
+
+def test_wide_neighbourhood_falls_back_when_the_class_minima_do_not_bound(device):
+    """156 near nodes that all sit in 20 of the 256 scan classes: the 100th smallest class minimum is a far node, more
+    than 256 keys lie under it, and the selection takes the general path; and duplicate points (equal roots at the
+    edge of the neighbourhood) through the one-pass path."""
+    rng = np.random.default_rng(3)
+    N = 2000
+    xy = (0.5 + 0.5 * rng.random((2, N, 2))).astype(np.float32)
+    near = np.array([j for j in range(500) if j % 64 < 20])
+    xy[:, near] = (0.1 + 0.02 * rng.random((2, near.size, 2))).astype(np.float32)
+    order = np.stack([np.concatenate((rng.permutation(near), np.setdiff1d(np.arange(N), near))) for _ in range(2)])
+    _run_case(device, xy, order, 100, check_until=12)
+    base = rng.random((2, 100, 2), dtype=np.float32)
+    dup = np.ascontiguousarray(np.repeat(base, 8, axis=1)[:, rng.permutation(800)])
+    _run_case(device, dup, np.stack([rng.permutation(800) for _ in range(2)]), 100, check_until=10)
+
+
 @pytest.mark.parametrize("N,until", [(5000, 40), (18512, 10)])
 def test_large_n(device, N, until):
     """18512 nodes: the largest instance of the reference's TSPLIB table (d18512, utils/utils.py:47-125)."""
