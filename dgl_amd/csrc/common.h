@@ -11,6 +11,7 @@
 
 // host-side error plumbing (api.cpp)
 int dgl_set_error(int code, const char *fmt, ...);
+const uint16_t *dgl_sqrt_table();                             // the current device's VRSQRT14 table, NULL: IEEE roots (api.cpp)
 void dgl_max_dynamic_lds(const void *kernel, int bytes);      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
 #define DGL_CHECK_ARG(cond, ...)                                           \
     do {                                                                   \
@@ -79,13 +80,55 @@ __device__ __forceinline__ float dgl_sqrt_pk(float x) {
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------- square-root models
+// Every square root on the decode path that the reference takes with torch.sqrt / torch.cdist (distance entries, the
+// running standard deviations) goes through a model object `sq`:
+//   DglSqrtIeee  the correctly rounded root (default);
+//   DglSqrtMkl   what those torch calls return on a CPU build of torch linked against MKL that runs on an AVX-512 machine
+//                (where the golden vectors were captured): MKL's vector sqrt refines the instruction VRSQRT14's estimate
+//                y once, s = x y, result = fma(fma(-s, s, x), y / 2, s), which is the correctly rounded root or - on
+//                0.6 % of all inputs, whenever the exact root lies less than 0.06 ulp above the midpoint of two floats -
+//                the float below it.  `tab` holds VRSQRT14 over [1, 4): 2^24 entries of 16 bits, index = exponent
+//                parity << 23 | mantissa (tools/make_rsqrt14_table.py; the estimate scales exactly with the exponent).
+//                Only inputs whose correctly rounded root was rounded up by more than 0.4 ulp can differ, so only those
+//                lanes look the estimate up.
+// sq(x): one root; sq.pk(x): the same value (the IEEE model evaluates its two residuals with one packed FMA there).
+// ULPS: how far above a bound on radicands a radicand can lie and still have a root that ties with the bound's.
+struct DglSqrtIeee {
+    static constexpr unsigned ULPS = 4u;
+    __device__ __forceinline__ float operator()(float x) const { return dgl_sqrt(x); }
+    __device__ __forceinline__ float pk(float x) const { return dgl_sqrt_pk(x); }
+};
+struct DglSqrtMkl {
+    static constexpr unsigned ULPS = 8u;
+    const uint16_t *tab;
+    __device__ __forceinline__ float operator()(float x) const {
+        const float s0 = dgl_sqrt(x);
+        const float ulp = __fsub_rn(s0, __uint_as_float(__float_as_uint(s0) - 1u));
+        const float r = __fmaf_rn(-s0, s0, x);                  // x - s0^2: root - s0 ~ r / (2 s0)
+        float res = s0;
+        if (r < -0.8f * __fmul_rn(s0, ulp)) {                   // the exact root lies more than 0.4 ulp below s0
+            const unsigned b = __float_as_uint(x);
+            const int e = (int)(b >> 23) - 127, p = e & 1, q = (e - p) >> 1;
+            const unsigned i = ((unsigned)p << 23) | (b & 0x7FFFFFu);
+            unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + ((unsigned)tab[i] << 7);
+            yb -= (unsigned)q << 23;
+            const float y = __uint_as_float(yb);
+            const float s = __fmul_rn(x, y), h = __fmul_rn(0.5f, y);
+            res = __fmaf_rn(__fmaf_rn(-s, s, x), h, s);
+        }
+        return res;
+    }
+    __device__ __forceinline__ float pk(float x) const { return (*this)(x); }
+};
+
 // One node's running mean / standard deviation of its distances to the unvisited nodes when the node at distance
 // dcol leaves that set (TSP/TSPEnv.py:386,408-409; CVRP/CVRPEnv.py:711,733-738): up1 = u + 1, du = division by u,
 //   avg' = (avg up1 - dcol) / u,   sd' = sqrt((sd^2 up1 - (dcol - avg)^2) / u)   (CLAMP: radicand < 0 -> 0).
 // The same roundings as the scalar formulas, with the two numerators and the two divisions in packed instructions.
-template <bool CLAMP>
+template <bool CLAMP, class SQ = DglSqrtIeee>
 __device__ __forceinline__ void dgl_update_moments(float dcol, float a0, float s0, float up1, const DglConstDiv &du,
-                                                   float *a1, float *s1) {
+                                                   float *a1, float *s1, const SQ &sq = SQ{}) {
     const float e = __fsub_rn(dcol, a0);
     const dgl_f2 num = dgl_f2{a0, __fmul_rn(s0, s0)} * dgl_splat2(up1) - dgl_f2{dcol, __fmul_rn(e, e)};
     const dgl_f2 q = num * dgl_splat2(du.rb);
@@ -94,7 +137,7 @@ __device__ __forceinline__ void dgl_update_moments(float dcol, float a0, float s
     float item = res.y;
     if (CLAMP && item < 0.0f) item = 0.0f;
     *a1 = res.x;
-    *s1 = dgl_sqrt_pk(item);
+    *s1 = sq.pk(item);
 }
 
 // |p|^2 as the reference's x.pow(2).sum(-1): two rounded products, one rounded add.
@@ -113,6 +156,10 @@ __device__ __forceinline__ float dgl_chain_sq(float cross, float ni, float nj) {
 }
 __device__ __forceinline__ float dgl_chain_dist(float xi, float yi, float ni, float xj, float yj, float nj) {
     return dgl_sqrt(dgl_chain_sq(dgl_chain_cross(xi, yi, xj, yj), ni, nj));
+}
+template <class SQ>
+__device__ __forceinline__ float dgl_chain_dist(const SQ &sq, float xi, float yi, float ni, float xj, float yj, float nj) {
+    return sq(dgl_chain_sq(dgl_chain_cross(xi, yi, xj, yj), ni, nj));
 }
 
 // v for the lanes whose bit is clear in the wave-uniform mask, +inf for the others: the mask

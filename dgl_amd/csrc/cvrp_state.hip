@@ -21,6 +21,15 @@ __global__ __launch_bounds__(256) void cvrp_reset_kernel(dgl_cvrp_state_t st) {
             st.capacity[(size_t)blockIdx.y * st.rows_per_instance + p] = 1.0f;
 }
 
+// the reset of the square-root models that reproduce the reference's torch build bit for bit: grid (ceil(M / 8), B)
+__global__ __launch_bounds__(256) void cvrp_reset_torch_kernel(dgl_cvrp_state_t st, DglSqrtMkl sq) {
+    dgl_reset_rows_torch(st.xy, st.demand_in_distance ? st.demand : nullptr, st.N + 1, st.rows_per_instance, st.avg, st.sd,
+                         st.visited, sq);
+    if (blockIdx.x == 0)
+        for (int p = threadIdx.x; p < st.rows_per_instance; p += blockDim.x)
+            st.capacity[(size_t)blockIdx.y * st.rows_per_instance + p] = 1.0f;
+}
+
 struct CvrpRowCtx {
     const float *xyb, *demb;
     float xc, yc, zc, nc, x0, y0, n0;       // current node (zc = its demand, used when D3), depot (demand 0)
@@ -43,15 +52,15 @@ __device__ __forceinline__ float cvrp_cross(float xi, float yi, float zi, float 
 
 // raw data row of a node at p with demand dem and running statistics (a, sd)
 // (CVRP/CVRPEnv.py:696,718,746,782,801); returns d(j, depot)
-template <bool D3>
-__device__ __forceinline__ float cvrp_row(const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
+template <bool D3, class SQ>
+__device__ __forceinline__ float cvrp_row(const SQ &sq, const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
     const float nj = cvrp_norm<D3>(p.x, p.y, dem);
-    const float d0 = dgl_chain_dist(p.x, p.y, nj, cx.x0, cx.y0, cx.n0);    // d(j, depot)
+    const float d0 = dgl_chain_dist(sq, p.x, p.y, nj, cx.x0, cx.y0, cx.n0);    // d(j, depot)
     const float den = __fadd_rn(d0, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
     f[2] = dem;
-    f[3] = dgl_sqrt(dgl_chain_sq(cvrp_cross<D3>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
+    f[3] = sq(dgl_chain_sq(cvrp_cross<D3>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
     f[4] = a;
     f[5] = sd;
     f[6] = __fdiv_rn(__fsub_rn(cx.y0, p.y), den);
@@ -59,9 +68,9 @@ __device__ __forceinline__ float cvrp_row(const CvrpRowCtx &cx, float2 p, float 
     return d0;
 }
 
-template <bool D3>
-__device__ __forceinline__ float cvrp_features(const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
-    return cvrp_row<D3>(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], cx.demb[j], st.avg[cx.rowM + j],
+template <bool D3, class SQ>
+__device__ __forceinline__ float cvrp_features(const SQ &sq, const dgl_cvrp_state_t &st, const CvrpRowCtx &cx, int j, float *f) {
+    return cvrp_row<D3>(sq, cx, reinterpret_cast<const float2 *>(cx.xyb)[j], cx.demb[j], st.avg[cx.rowM + j],
                     st.sd[cx.rowM + j], f);
 }
 
@@ -84,14 +93,14 @@ struct CvrpBeamLink {
     int32_t *hist_action, *hist_parent;    // [N][R], entry (t - 1) * R + r
 };
 
-template <int WAVES, bool UPDATE, bool D3, bool SPLIT = false>
+template <class SQ, int WAVES, bool UPDATE, bool D3, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) void cvrp_step_kernel(dgl_cvrp_state_t st, const int32_t *__restrict__ action,
                                                               int t, int knn, int depot_knn,
                                                               int32_t *__restrict__ idx_last_out,
                                                               int32_t *__restrict__ idx_dep_out,
                                                               uint8_t *__restrict__ infeasible_out,
                                                               float *__restrict__ tile_out, int lds_per_wave,
-                                                              CvrpBeamLink link) {
+                                                              CvrpBeamLink link, SQ sq) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar registers
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
@@ -171,14 +180,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
                 const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3>(x, y, g.dm[q]);
                 const float cross = cvrp_cross<D3>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
-                    const float dcol = dgl_sqrt(dgl_chain_sq(cross, nj, cx.nc));                  // dis[j][cur]
+                    const float dcol = sq(dgl_chain_sq(cross, nj, cx.nc));                        // dis[j][cur]
                     const float a0 = g.a0[q], s0 = g.s0[q];
                     const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);             // :711
                     const float e = __fsub_rn(dcol, a0);
                     float item = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
                     if (item < 0.0f) item = 0.0f;                                                   // :735-736
                     avg[j] = a1;
-                    sd[j] = dgl_sqrt(item);
+                    sd[j] = sq(item);
                 }
                 if (want_knn) {
                     // keys are squared distances dis[cur][j]^2 and dis[0][j]^2; visited nodes, the current
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         if (share) {
             float *lw = scratch + 256 + 2 * WAVES * 64;
             int *cw = reinterpret_cast<int *>(lw + 2 * WAVES * 128);
-            boundL = __uint_as_float(wave_candidate_bound(minL, kl));
-            boundD = __uint_as_float(wave_candidate_bound(minD, kd));
+            boundL = __uint_as_float(wave_candidate_bound(minL, kl, SQ::ULPS));
+            boundD = __uint_as_float(wave_candidate_bound(minD, kd, SQ::ULPS));
             float *mine = lw + 128 * wave;
             const int cl = wave_compact(keysL, j_begin, j_end, boundL, mine, reinterpret_cast<int *>(mine) + 64);
             mine += 128 * WAVES;
@@ -291,8 +300,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
     int cj;
     int c = -1;
     if (do_last) {
-    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysL, M, kl, boundL, scratch, &ckey, &cj)
-              : wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj);
+    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysL, M, kl, boundL, scratch, &ckey, &cj, SQ::ULPS)
+              : wave_candidates(keysL, M, kl, minL, scratch, &ckey, &cj, SQ::ULPS);
     if (c >= 0) {
         // inputs of every candidate's row (and of the anchor, on lane 63 when it holds no candidate)
         // are requested before the ranking bisection
@@ -301,68 +310,68 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kl, &rank);
+        const bool pick = wave_pick_k(sq(ckey), c, kl, &rank);
         if (pick || anchor_early) {
             float *f = tileL + (pick ? rank : kl) * DGL_TILE_STRIDE;
-            cvrp_row<D3>(cx, p, dm, av, sv, f);
+            cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
             if (pick) {
                 il[rank] = cj;
                 finish_last(f, rank);
             }
         }
-        if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) cvrp_features<D3>(sq, st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     } else {
         auto emit_last = [&](int j, int rank) {
             il[rank] = j;
             float *f = tileL + rank * DGL_TILE_STRIDE;
-            cvrp_features<D3>(st, cx, j, f);
+            cvrp_features<D3>(sq, st, cx, j, f);
             finish_last(f, rank);
         };
-        if (!(SPLIT && kl > 64 && kl <= 256 && wave_select_wide<WAVES>(keysL, M, kl, wide_min, wide_list, emit_last)))
-        wave_select_general(keysL, M, kl, scratch, [&](int j, int rank) {
+        if (!(SPLIT && kl > 64 && kl <= 256 && wave_select_wide<WAVES>(sq, keysL, M, kl, wide_min, wide_list, emit_last)))
+        wave_select_general(sq, keysL, M, kl, scratch, [&](int j, int rank) {
             il[rank] = j;
             float *f = tileL + rank * DGL_TILE_STRIDE;
-            cvrp_features<D3>(st, cx, j, f);
+            cvrp_features<D3>(sq, st, cx, j, f);
             finish_last(f, rank);
         });
-        if (lane == 63) cvrp_features<D3>(st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
+        if (lane == 63) cvrp_features<D3>(sq, st, cx, cur, tileL + kl * DGL_TILE_STRIDE);
     }
     for (int e = kl + lane; e < knn; e += 64) { il[e] = -1; inf_row[e] = 0; }
     wave_lds_sync();                                           // scratch is reused by the second search
     }
     if (do_depot) {
     // neighbourhood of the depot: column 3 holds distance_to_depot (CVRP/CVRPModel.py:180-183)
-    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysD, M, kd, boundD, scratch, &ckey, &cj)
-              : wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj);
+    c = share ? wave_candidates_from_lists(lists, counts, WAVES, keysD, M, kd, boundD, scratch, &ckey, &cj, SQ::ULPS)
+              : wave_candidates(keysD, M, kd, minD, scratch, &ckey, &cj, SQ::ULPS);
     if (c >= 0) {
         const bool anchor_early = (c < 64) && (lane == 63);
         const int jl = anchor_early ? 0 : cj;
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, kd, &rank);
+        const bool pick = wave_pick_k(sq(ckey), c, kd, &rank);
         if (pick || anchor_early) {
             float *f = tileD + (pick ? rank : kd) * DGL_TILE_STRIDE;
-            const float d0 = cvrp_row<D3>(cx, p, dm, av, sv, f);
+            const float d0 = cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
             if (pick) {
                 id[rank] = cj;
                 f[3] = d0;
             }
         }
-        if (c == 64 && lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) cvrp_features<D3>(sq, st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     } else {
         auto emit_depot = [&](int j, int rank) {
             id[rank] = j;
             float *f = tileD + rank * DGL_TILE_STRIDE;
-            f[3] = cvrp_features<D3>(st, cx, j, f);
+            f[3] = cvrp_features<D3>(sq, st, cx, j, f);
         };
-        if (!(SPLIT && kd > 64 && kd <= 256 && wave_select_wide<WAVES>(keysD, M, kd, wide_min, wide_list, emit_depot)))
-        wave_select_general(keysD, M, kd, scratch, [&](int j, int rank) {
+        if (!(SPLIT && kd > 64 && kd <= 256 && wave_select_wide<WAVES>(sq, keysD, M, kd, wide_min, wide_list, emit_depot)))
+        wave_select_general(sq, keysD, M, kd, scratch, [&](int j, int rank) {
             id[rank] = j;
             float *f = tileD + rank * DGL_TILE_STRIDE;
-            f[3] = cvrp_features<D3>(st, cx, j, f);
+            f[3] = cvrp_features<D3>(sq, st, cx, j, f);
         });
-        if (lane == 63) cvrp_features<D3>(st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
+        if (lane == 63) cvrp_features<D3>(sq, st, cx, 0, tileD + kd * DGL_TILE_STRIDE);
     }
     for (int e = kd + lane; e < depot_knn; e += 64) id[e] = -1;
     wave_lds_sync();
@@ -377,8 +386,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
-template <bool D3>
-__global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__restrict__ out) {
+template <bool D3, class SQ>
+__global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__restrict__ out, SQ sq) {
     const int r = blockIdx.y, N = st.N, M = N + 1;
     const int b = r / st.rows_per_instance;
     CvrpRowCtx cx;
@@ -390,7 +399,7 @@ __global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__rest
     cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
         float f[CVRP_F];
-        cvrp_features<D3>(st, cx, j, f);
+        cvrp_features<D3>(sq, st, cx, j, f);
         float *o = out + (cx.rowM + j) * CVRP_F;
 #pragma unroll
         for (int c = 0; c < CVRP_F; ++c) o[c] = f[c];
@@ -461,6 +470,14 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     const int M = st->N + 1;
     size_t lds = (size_t)M * (st->demand_in_distance ? 3 : 2) * sizeof(float);
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset", st->N);
+    if (const uint16_t *tab = dgl_sqrt_table()) {
+        if (lds > 48 * 1024)
+            dgl_max_dynamic_lds((const void *)cvrp_reset_torch_kernel, (int)lds);
+        hipLaunchKernelGGL(cvrp_reset_torch_kernel, dim3((M + 7) / 8, st->B), dim3(256), lds, (hipStream_t)stream, *st,
+                           DglSqrtMkl{tab});
+        DGL_CHECK_LAUNCH("dgl_cvrp_reset");
+        return DGL_OK;
+    }
     if (lds > 48 * 1024)
         dgl_max_dynamic_lds((const void *)cvrp_reset_kernel, (int)lds);
     hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 255) / 256, st->B), dim3(256), lds, (hipStream_t)stream, *st);
@@ -468,10 +485,10 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     return DGL_OK;
 }
 
-template <bool UPDATE, bool D3>
-static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
-                            int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
-                            dgl_stream_t stream, const char *what, const CvrpBeamLink &link = CvrpBeamLink{}) {
+template <bool UPDATE, bool D3, class SQ>
+static int launch_cvrp_step_sq(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                               int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                               dgl_stream_t stream, const char *what, const CvrpBeamLink &link, SQ sq) {
     const int M = st->N + 1;
     const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
@@ -484,32 +501,44 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
         // few rows: four (or eight) waves share a row
         if (waves == 8) {
             if (lds_split > 48 * 1024)
-                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<8, UPDATE, D3, true>, (int)lds_split);
-            hipLaunchKernelGGL((cvrp_step_kernel<8, UPDATE, D3, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
+                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<SQ, 8, UPDATE, D3, true>, (int)lds_split);
+            hipLaunchKernelGGL((cvrp_step_kernel<SQ, 8, UPDATE, D3, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
                                *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                               per_wave, link);
+                               per_wave, link, sq);
         } else {
             if (lds_split > 48 * 1024)
-                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<4, UPDATE, D3, true>, (int)lds_split);
-            hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                dgl_max_dynamic_lds((const void *)cvrp_step_kernel<SQ, 4, UPDATE, D3, true>, (int)lds_split);
+            hipLaunchKernelGGL((cvrp_step_kernel<SQ, 4, UPDATE, D3, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
                                *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                               per_wave, link);
+                               per_wave, link, sq);
         }
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
-        hipLaunchKernelGGL((cvrp_step_kernel<4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
+        hipLaunchKernelGGL((cvrp_step_kernel<SQ, 4, UPDATE, D3>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
                            *st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out,
-                           per_wave, link);
+                           per_wave, link, sq);
     } else {
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
                       depot_knn, lds1);
         if (lds1 > 48 * 1024)
-            dgl_max_dynamic_lds((const void *)cvrp_step_kernel<1, UPDATE, D3>, (int)lds1);
-        hipLaunchKernelGGL((cvrp_step_kernel<1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
-                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave, link);
+            dgl_max_dynamic_lds((const void *)cvrp_step_kernel<SQ, 1, UPDATE, D3>, (int)lds1);
+        hipLaunchKernelGGL((cvrp_step_kernel<SQ, 1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
+                           t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave, link, sq);
     }
     DGL_CHECK_LAUNCH(what);
     return DGL_OK;
+}
+
+// the square-root model in force on the current device picks the instantiation (dgl_set_sqrt_model)
+template <bool UPDATE, bool D3>
+static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                            int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                            dgl_stream_t stream, const char *what, const CvrpBeamLink &link = CvrpBeamLink{}) {
+    if (const uint16_t *tab = dgl_sqrt_table())
+        return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                               tile_out, stream, what, link, DglSqrtMkl{tab});
+    return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                           tile_out, stream, what, link, DglSqrtIeee{});
 }
 
 extern "C" int dgl_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn,
@@ -604,10 +633,14 @@ extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float 
     DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
     DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
     dim3 grid(min((st->N + 256) / 256, 64), st->R);
-    if (st->demand_in_distance)
-        hipLaunchKernelGGL(cvrp_state_data_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
-    else
-        hipLaunchKernelGGL(cvrp_state_data_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    auto go = [&](auto sq) {
+        using SQ = decltype(sq);
+        if (st->demand_in_distance)
+            hipLaunchKernelGGL((cvrp_state_data_kernel<true, SQ>), grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, sq);
+        else
+            hipLaunchKernelGGL((cvrp_state_data_kernel<false, SQ>), grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, sq);
+    };
+    if (const uint16_t *tab = dgl_sqrt_table()) go(DglSqrtMkl{tab}); else go(DglSqrtIeee{});
     DGL_CHECK_LAUNCH("dgl_cvrp_state_data");
     return DGL_OK;
 }

@@ -437,6 +437,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
         STAMP2();
 
         // ---- multi_head_combine + residual -> o1 -------------------------------------
+        // (every wave passed the barrier above after its Q/K/V reads of X: X may be replaced)
         {
             f32x16 acc[ROWS];
 #pragma unroll
@@ -450,7 +451,6 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (acc[rr][4 * g + e] + bb[e]);
             }
-            // every wave passed the barrier above after its Q/K/V reads of X: X may be replaced
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);
         }
@@ -556,6 +556,7 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
             STAMP2();
             __syncthreads();
             STAMP2();
+            // the last barrier came after every wave's last read of X (W1 of chunk 3): X may be replaced
             gemm16_t<ROWS, ROWH, 176, DGL_W2_PASSES>(ring, CH + rd, CL + rd, af);                                      // G2(3)
             STAMP2();
 #pragma unroll
@@ -566,7 +567,6 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
 #pragma unroll
                     for (int rr = 0; rr < ROWS; ++rr) xres[rr][4 * g + e] = xres[rr][4 * g + e] + (af[rr][4 * g + e] + b2[e]);
             }
-            // the last barrier came after every wave's last read of X (W1 of chunk 3)
             if (layer < 3) {
 #pragma unroll
                 for (int rr = 0; rr < ROWS; ++rr) store_split(xres[rr], XH + rr * ROWH + wr, XL + rr * ROWH + wr, range_mx);

@@ -80,7 +80,7 @@ __device__ __forceinline__ int wave_count_le(float v, unsigned x) { return __pop
 // concatenation of per-wave lists) are separate so that the waves sharing a row can split the work.
 //
 // the bound of step 1 as a bit pattern (k <= 64)
-__device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k) {
+__device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k, unsigned ulps = 4u) {
     const unsigned FMAX = 0x7F7FFFFFu;
     unsigned hi = FMAX;                     // fewer than k finite lane minima: every finite key is a candidate
     if (wave_count_le(lane_min, FMAX) >= k) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned wave_candidate_bound(float lane_min, int k) 
                 lo = mid;
             }
         }
-        hi = min(hi + 4u, FMAX);
+        hi = min(hi + ulps, FMAX);
     }
     return hi;
 }
@@ -134,9 +134,9 @@ __device__ __forceinline__ int wave_compact(const float *keys, int j_lo, int j_h
 // under their k-th smallest too, so it bounds the row's k-th smallest from above, and all but a few of the surplus
 // keys lie above it.  One more pass over the row's keys with that bound.
 __device__ __forceinline__ int wave_candidates_again(const float *keys, int n, int k, float first_key, float bound,
-                                                     float *scratch, float *key_out, int *j_out) {
+                                                     float *scratch, float *key_out, int *j_out, unsigned ulps = 4u) {
     const int lane = threadIdx.x & 63;
-    bound = fminf(bound, __uint_as_float(wave_candidate_bound(first_key, k)));
+    bound = fminf(bound, __uint_as_float(wave_candidate_bound(first_key, k, ulps)));
     int *cand_j = reinterpret_cast<int *>(scratch) + 64;
     wave_lds_sync();                        // every lane has read its first_key (it may come from scratch)
     const int c = wave_compact(keys, 0, n, bound, scratch, cand_j);
@@ -148,14 +148,14 @@ __device__ __forceinline__ int wave_candidates_again(const float *keys, int n, i
 }
 
 __device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, float lane_min, float *scratch,
-                                               float *key_out, int *j_out) {
+                                               float *key_out, int *j_out, unsigned ulps = 4u) {
     const int lane = threadIdx.x & 63;
     if (k > 64) return -1;
-    const float bound = __uint_as_float(wave_candidate_bound(lane_min, k));
+    const float bound = __uint_as_float(wave_candidate_bound(lane_min, k, ulps));
     int *cand_j = reinterpret_cast<int *>(scratch) + 64;
     const int c = wave_compact(keys, 0, n, bound, scratch, cand_j);
     wave_lds_sync();
-    if (c > 64) return wave_candidates_again(keys, n, k, scratch[lane], bound, scratch, key_out, j_out);
+    if (c > 64) return wave_candidates_again(keys, n, k, scratch[lane], bound, scratch, key_out, j_out, ulps);
     *key_out = lane < c ? scratch[lane] : INFINITY;
     *j_out = lane < c ? cand_j[lane] : 0;
     return c;
@@ -166,7 +166,7 @@ __device__ __forceinline__ int wave_candidates(const float *keys, int n, int k, 
 // ascend with w, so the lists concatenate in index order.  Called by one wave after the workgroup barrier.
 __device__ __forceinline__ int wave_candidates_from_lists(const float *lists, const int *counts, int W, const float *keys,
                                                           int n, int k, float bound, float *scratch, float *key_out,
-                                                          int *j_out) {
+                                                          int *j_out, unsigned ulps = 4u) {
     const int lane = threadIdx.x & 63;
     int c = 0;
     float key = INFINITY;
@@ -179,7 +179,7 @@ __device__ __forceinline__ int wave_candidates_from_lists(const float *lists, co
         }
         c += cw;
     }
-    if (c > 64) return wave_candidates_again(keys, n, k, key, bound, scratch, key_out, j_out);
+    if (c > 64) return wave_candidates_again(keys, n, k, key, bound, scratch, key_out, j_out, ulps);
     *key_out = key;
     *j_out = j;
     return c;
@@ -224,9 +224,9 @@ __device__ __forceinline__ bool wave_pick_k(float root, int c, int k, int *rank_
 // 256 keys, 256 indices), four per lane (slot 64 q + lane); their roots are ranked as in wave_pick_k.  emit(j, rank) is
 // called for the k picks, rank ascending with the node index.  Returns false - nothing emitted - when the class minima
 // cannot bound k keys or more than 256 keys lie under the bound: the caller then takes the general path.
-template <int W, class Emit>
-__device__ __forceinline__ bool wave_select_wide(const float *keys, int n, int k, const float *class_min, float *list,
-                                                 Emit emit) {
+template <int W, class SQ, class Emit>
+__device__ __forceinline__ bool wave_select_wide(const SQ &sq, const float *keys, int n, int k, const float *class_min,
+                                                 float *list, Emit emit) {
     const int lane = threadIdx.x & 63;
     const unsigned FMAX = 0x7F7FFFFFu;
     float m[W];
@@ -251,7 +251,7 @@ __device__ __forceinline__ bool wave_select_wide(const float *keys, int n, int k
             lo = mid;
         }
     }
-    const float bound = __uint_as_float(min(hi + 4u, FMAX));
+    const float bound = __uint_as_float(min(hi + SQ::ULPS, FMAX));
     int *list_j = reinterpret_cast<int *>(list) + 256;
     const int c = wave_compact(keys, 0, n, bound, list, list_j, 256);
     if (c > 256) return false;
@@ -262,7 +262,7 @@ __device__ __forceinline__ bool wave_select_wide(const float *keys, int n, int k
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int s = 64 * q + lane;
-        root[q] = s < c ? dgl_sqrt(list[s]) : INFINITY;
+        root[q] = s < c ? sq(list[s]) : INFINITY;
         cj[q] = s < c ? list_j[s] : 0;
         pick[q] = s < c;
     }
@@ -313,10 +313,10 @@ __device__ __forceinline__ bool wave_select_wide(const float *keys, int n, int k
 
 // General path: all keys are rooted in place, then bisection over all keys + the two ballot scans
 // of wave_emit_selected.  emit(j, rank) is called by the lane that owns j (j % 64 == lane).
-template <class Emit>
-__device__ __forceinline__ void wave_select_general(float *keys, int n, int k, float *scratch, Emit emit) {
+template <class SQ, class Emit>
+__device__ __forceinline__ void wave_select_general(const SQ &sq, float *keys, int n, int k, float *scratch, Emit emit) {
     const int lane = threadIdx.x & 63;
-    for (int j = lane; j < n; j += 64) keys[j] = dgl_sqrt(keys[j]);    // each lane roots the keys it wrote
+    for (int j = lane; j < n; j += 64) keys[j] = sq(keys[j]);    // each lane roots the keys it wrote
     wave_lds_sync();
     const float T = wave_kth_smallest(keys, n, k, scratch);
     wave_emit_selected(keys, n, k, T, emit);

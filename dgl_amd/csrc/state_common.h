@@ -90,3 +90,111 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, con
         for (int e = threadIdx.x; e < rows_per_instance * W; e += blockDim.x) visited[base + e] = 0ull;
     }
 }
+
+// The same reset with torch's own arithmetic for the row means, for the square-root models that aim at the reference's
+// bits (DglSqrtMkl): torch.mean over the last dimension of a contiguous float matrix is ATen's cascade sum
+// (aten/src/ATen/native/cpu/SumKernel.cpp) with 8-lane vectors, whatever the CPU: a row of M floats is read as
+// M / 8 vectors; four interleaved vector accumulators (element j of the first 32 (M / 32) goes to accumulator
+// (j / 8) % 4, lane j % 8) each sum their sequence through a cascade that folds level 0 into level 1 after every 16
+// terms, level 1 into level 2 after every 256, ...; the left-over vectors go to accumulator 0, accumulators 1..3 are
+// added to it in order, then a scalar adds the row's last M % 8 elements and the eight lanes, in that order; the mean is
+// that sum divided by M in binary32 (checked bit for bit against torch.mean for M = 27 ... 10 000).  torch.std
+// accumulates in binary64 and is the correctly rounded population std of the binary32 distances: sums in binary64 here.
+// Half a wave owns one node i: lane (k, v) = accumulator k, lane v.  grid: (ceil(M / 8), B), block 256 (8 nodes).
+template <class SQ>
+__device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ xy, const float *__restrict__ z, int M,
+                                                     int rows_per_instance, float *__restrict__ avg, float *__restrict__ sd,
+                                                     uint64_t *__restrict__ visited, const SQ &sq) {
+    extern __shared__ float lds_xy[];   // [M][2] (+ [M] third coordinates)
+    const int b = blockIdx.y;
+    const float *xyb = xy + (size_t)b * M * 2;
+    for (int e = threadIdx.x; e < 2 * M; e += blockDim.x) lds_xy[e] = xyb[e];
+    float *lds_z = lds_xy + 2 * M;
+    if (z)
+        for (int e = threadIdx.x; e < M; e += blockDim.x) lds_z[e] = z[(size_t)b * M + e];
+    __syncthreads();
+    const int l = threadIdx.x & 31, k = l >> 3, v = l & 7;
+    const int i = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    const bool live = i < M;
+    const int ii = live ? i : 0;
+    const float2 *pts = reinterpret_cast<const float2 *>(lds_xy);
+    const float xi = pts[ii].x, yi = pts[ii].y, zi = z ? lds_z[ii] : 0.0f;
+    const float ni = z ? __fadd_rn(dgl_sqnorm(xi, yi), __fmul_rn(zi, zi)) : dgl_sqnorm(xi, yi);
+    auto dist = [&](int j) {
+        const float2 pj = pts[j];
+        float cross = dgl_chain_cross(xi, yi, pj.x, pj.y), nj = dgl_sqnorm(pj.x, pj.y);
+        if (z) {
+            const float zj = lds_z[j];
+            cross = __fmaf_rn(-2.0f * zi, zj, cross);
+            nj = __fadd_rn(nj, __fmul_rn(zj, zj));
+        }
+        return sq(dgl_chain_sq(cross, ni, nj));
+    };
+    const int vec_size = M / 8, size_ilp = vec_size / 4;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // cascade levels (level step 16 up to 2^19 vectors per accumulator)
+    double s64 = 0.0, q64 = 0.0;
+    int t = 0;
+    while (t + 16 <= size_ilp) {
+        for (int u = 0; u < 16; ++u, ++t) {
+            const float d = dist(32 * t + l);
+            a0 = __fadd_rn(a0, d);
+            s64 += (double)d;
+            q64 = fma((double)d, (double)d, q64);
+        }
+        a1 = __fadd_rn(a1, a0); a0 = 0.0f;
+        if ((t & (15 << 4)) == 0) {
+            a2 = __fadd_rn(a2, a1); a1 = 0.0f;
+            if ((t & (15 << 8)) == 0) { a3 = __fadd_rn(a3, a2); a2 = 0.0f; }
+        }
+    }
+    for (; t < size_ilp; ++t) {
+        const float d = dist(32 * t + l);
+        a0 = __fadd_rn(a0, d);
+        s64 += (double)d;
+        q64 = fma((double)d, (double)d, q64);
+    }
+    a0 = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+    // left-over vectors: accumulator 0 only
+    for (int w = 4 * size_ilp; w < vec_size; ++w) {
+        if (k == 0) {
+            const float d = dist(8 * w + v);
+            a0 = __fadd_rn(a0, d);
+            s64 += (double)d;
+            q64 = fma((double)d, (double)d, q64);
+        }
+    }
+    // accumulators 1, 2, 3 into accumulator 0 (lanes k = 0 of this half wave), in that order
+    const int base = threadIdx.x & 32;                         // first lane of this half of the wave
+    float p0 = a0;
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk) p0 = __fadd_rn(p0, __shfl(a0, base + 8 * kk + v, 64));
+    // scalar tail, then the eight lanes in order
+    float total = 0.0f;
+    for (int j = 8 * vec_size; j < M; ++j) {
+        const float d = dist(j);
+        total = __fadd_rn(total, d);
+        if (l == 0) { s64 += (double)d; q64 = fma((double)d, (double)d, q64); }
+    }
+#pragma unroll
+    for (int vv = 0; vv < 8; ++vv) total = __fadd_rn(total, __shfl(p0, base + vv, 64));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {                          // binary64 sums over the half wave
+        s64 += __shfl_xor(s64, o, 64);
+        q64 += __shfl_xor(q64, o, 64);
+    }
+    if (live && l == 0) {
+        const float favg = __fdiv_rn(total, (float)M);
+        const double mean = s64 / M, var = q64 / M - mean * mean;
+        const float fsd = (float)sqrt(var > 0.0 ? var : 0.0);
+        for (int p = 0; p < rows_per_instance; ++p) {
+            const size_t r = (size_t)b * rows_per_instance + p;
+            avg[r * M + i] = favg;
+            sd[r * M + i] = fsd;
+        }
+    }
+    if (blockIdx.x == 0) {
+        const int W = (M + 63) / 64;
+        size_t base_w = (size_t)b * rows_per_instance * W;
+        for (int e = threadIdx.x; e < rows_per_instance * W; e += blockDim.x) visited[base_w + e] = 0ull;
+    }
+}

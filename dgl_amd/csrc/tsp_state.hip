@@ -16,22 +16,29 @@ __global__ __launch_bounds__(256) void tsp_reset_kernel(dgl_tsp_state_t st) {
     dgl_reset_rows(st.xy, nullptr, st.N, st.rows_per_instance, st.avg, st.sd, st.visited);
 }
 
+// the reset of the square-root models that reproduce the reference's torch build bit for bit: grid (ceil(N / 8), B)
+__global__ __launch_bounds__(256) void tsp_reset_torch_kernel(dgl_tsp_state_t st, DglSqrtMkl sq) {
+    dgl_reset_rows_torch(st.xy, nullptr, st.N, st.rows_per_instance, st.avg, st.sd, st.visited, sq);
+}
+
 // ---------------------------------------------------------------------------- step
 // (body: tsp_step_body.h)  One wave per row, or the WAVES waves of a workgroup sharing one row (SPLIT).
-template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false>
+template <class SQ, int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false>
 __global__ __launch_bounds__(WAVES * 64) void tsp_step_kernel(dgl_tsp_state_t st, const int32_t *__restrict__ selected,
                                                              int t, int knn, int32_t *__restrict__ idx_out,
                                                              float *__restrict__ tile_out, int lds_per_wave, int mom_off,
-                                                             TspBeamLink link) {
+                                                             TspBeamLink link, SQ sq) {
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar registers
     const int r = SPLIT ? blockIdx.x : blockIdx.x * WAVES + wave;
     if (r >= st.R) return;                                  // uniform over the waves that meet at a barrier
-    tsp_step_row<WAVES, UPDATE, SPLIT, STREAM>(st, selected, t, knn, idx_out, tile_out, lds_per_wave, mom_off, link, lds, r, wave);
+    tsp_step_row<WAVES, UPDATE, SPLIT, STREAM, false, SQ>(st, selected, t, knn, idx_out, tile_out, lds_per_wave, mom_off, link,
+                                                          lds, r, wave, sq);
 }
 
 // ---------------------------------------------------------------- dense state (API parity)
-__global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restrict__ out) {
+template <class SQ>
+__global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restrict__ out, SQ sq) {
     const int r = blockIdx.y;
     const int N = st.N;
     TspRowCtx cx;
@@ -42,7 +49,7 @@ __global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restri
     cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
         float f[TSP_F];
-        tsp_features(st, cx, j, f);
+        tsp_features(sq, st, cx, j, f);
         float *o = out + (cx.rowN + j) * TSP_F;
 #pragma unroll
         for (int c = 0; c < TSP_F; ++c) o[c] = f[c];
@@ -84,6 +91,24 @@ __global__ __launch_bounds__(256) void tsp_permute_kernel(dgl_tsp_state_t src, d
     for (int w = threadIdx.x; w < W; w += blockDim.x) dst.visited[(size_t)r * W + w] = src.visited[(size_t)sr * W + w];
 }
 
+// ------------------------------------------------------------------ square-root model check
+template <class SQ>
+__global__ void sqrt_apply_kernel(const float *__restrict__ x, float *__restrict__ out, long long n, SQ sq) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = sq(x[i]);
+}
+
+extern "C" int dgl_sqrt_apply(const float *x, float *out, int64_t n, dgl_stream_t stream) {
+    DGL_CHECK_ARG(x != nullptr && out != nullptr && n >= 0, "NULL argument or n < 0");
+    if (n == 0) return DGL_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (const uint16_t *tab = dgl_sqrt_table())
+        hipLaunchKernelGGL(sqrt_apply_kernel<DglSqrtMkl>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, DglSqrtMkl{tab});
+    else
+        hipLaunchKernelGGL(sqrt_apply_kernel<DglSqrtIeee>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, DglSqrtIeee{});
+    DGL_CHECK_LAUNCH("dgl_sqrt_apply");
+    return DGL_OK;
+}
+
 // ------------------------------------------------------------------------ launchers
 static int check_tsp_state(const dgl_tsp_state_t *st) {
     DGL_CHECK_ARG(st != nullptr, "state is NULL");
@@ -105,15 +130,23 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
     if (lds > 48 * 1024)
         dgl_max_dynamic_lds((const void *)tsp_reset_kernel, (int)lds);
+    if (const uint16_t *tab = dgl_sqrt_table()) {
+        if (lds > 48 * 1024)
+            dgl_max_dynamic_lds((const void *)tsp_reset_torch_kernel, (int)lds);
+        hipLaunchKernelGGL(tsp_reset_torch_kernel, dim3((st->N + 7) / 8, st->B), dim3(256), lds, (hipStream_t)stream, *st,
+                           DglSqrtMkl{tab});
+        DGL_CHECK_LAUNCH("dgl_tsp_reset");
+        return DGL_OK;
+    }
     dim3 grid((st->N + 255) / 256, st->B);
     hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_tsp_reset");
     return DGL_OK;
 }
 
-template <bool UPDATE>
-static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
-                           float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
+template <bool UPDATE, class SQ>
+static int launch_tsp_step_sq(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                              float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link, SQ sq) {
     const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
     size_t lds4 = (size_t)per_wave * 4 * sizeof(float);
     // shared-row shape, rows of up to 2048 nodes: 8 N more bytes of LDS hold the new (avg, sd) pairs
@@ -133,32 +166,41 @@ static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, i
     if (split && lds_split <= 150 * 1024) {
         // few rows: four waves share a row
         if (lds_split > 48 * 1024)
-            dgl_max_dynamic_lds((const void *)tsp_step_kernel<4, UPDATE, true>, (int)lds_split);
+            dgl_max_dynamic_lds((const void *)tsp_step_kernel<SQ, 4, UPDATE, true>, (int)lds_split);
         static const int force_stream = getenv("DGL_STEP_STREAM") ? atoi(getenv("DGL_STEP_STREAM")) : -1;          // experiments
         if (waves == 8) {
             if (lds_split > 48 * 1024)
-                dgl_max_dynamic_lds((const void *)tsp_step_kernel<8, UPDATE, true>, (int)lds_split);
-            hipLaunchKernelGGL((tsp_step_kernel<8, UPDATE, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
-                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+                dgl_max_dynamic_lds((const void *)tsp_step_kernel<SQ, 8, UPDATE, true>, (int)lds_split);
+            hipLaunchKernelGGL((tsp_step_kernel<SQ, 8, UPDATE, true>), dim3(st->R), dim3(512), lds_split, (hipStream_t)stream,
+                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link, sq);
         } else if (with_mom && lds_split <= 48 * 1024 && (force_stream >= 0 ? force_stream != 0 : (long long)st->R * st->N >= 16000000ll))
-            hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true, true>), dim3(st->R), dim3(256), lds_split,
-                               (hipStream_t)stream, *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+            hipLaunchKernelGGL((tsp_step_kernel<SQ, 4, UPDATE, true, true>), dim3(st->R), dim3(256), lds_split,
+                               (hipStream_t)stream, *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link, sq);
         else
-            hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
-                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link);
+            hipLaunchKernelGGL((tsp_step_kernel<SQ, 4, UPDATE, true>), dim3(st->R), dim3(256), lds_split, (hipStream_t)stream,
+                               *st, selected, t, knn, idx_out, tile_out, per_wave, mom_off, link, sq);
     } else if (lds4 <= 64 * 1024 && st->R >= 2048) {
-        hipLaunchKernelGGL((tsp_step_kernel<4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
-                           *st, selected, t, knn, idx_out, tile_out, per_wave, 0, link);
+        hipLaunchKernelGGL((tsp_step_kernel<SQ, 4, UPDATE>), dim3((st->R + 3) / 4), dim3(256), lds4, (hipStream_t)stream,
+                           *st, selected, t, knn, idx_out, tile_out, per_wave, 0, link, sq);
     } else {
         size_t lds1 = (size_t)per_wave * sizeof(float);
         DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
         if (lds1 > 48 * 1024)
-            dgl_max_dynamic_lds((const void *)tsp_step_kernel<1, UPDATE>, (int)lds1);
-        hipLaunchKernelGGL((tsp_step_kernel<1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
-                           selected, t, knn, idx_out, tile_out, per_wave, 0, link);
+            dgl_max_dynamic_lds((const void *)tsp_step_kernel<SQ, 1, UPDATE>, (int)lds1);
+        hipLaunchKernelGGL((tsp_step_kernel<SQ, 1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
+                           selected, t, knn, idx_out, tile_out, per_wave, 0, link, sq);
     }
     DGL_CHECK_LAUNCH(what);
     return DGL_OK;
+}
+
+// the square-root model in force on the current device picks the instantiation (dgl_set_sqrt_model)
+template <bool UPDATE>
+static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                           float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
+    if (const uint16_t *tab = dgl_sqrt_table())
+        return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMkl{tab});
+    return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtIeee{});
 }
 
 extern "C" int dgl_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn,
@@ -227,7 +269,10 @@ extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *d
     DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
     DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
     dim3 grid(min((st->N + 255) / 256, 64), st->R);
-    hipLaunchKernelGGL(tsp_state_data_kernel, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out);
+    if (const uint16_t *tab = dgl_sqrt_table())
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMkl>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMkl{tab});
+    else
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtIeee>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtIeee{});
     DGL_CHECK_LAUNCH("dgl_tsp_state_data");
     return DGL_OK;
 }

@@ -16,21 +16,23 @@ struct TspRowCtx {
 
 // raw feature row of a node at p with running statistics (a, sd): x, y, d(j,cur), avg, sd and
 // sin/cos of the direction towards the start node (TSP/TSPEnv.py:371,393,415,430-475)
-__device__ __forceinline__ void tsp_row(const TspRowCtx &cx, float2 p, float a, float sd, float *f) {
+template <class SQ>
+__device__ __forceinline__ void tsp_row(const SQ &sq, const TspRowCtx &cx, float2 p, float a, float sd, float *f) {
     const float nj = dgl_sqnorm(p.x, p.y);
-    const float ds = dgl_chain_dist(p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
+    const float ds = dgl_chain_dist(sq, p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
     const float den = __fadd_rn(ds, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
-    f[2] = dgl_chain_dist(p.x, p.y, nj, cx.xc, cx.yc, cx.nc);                  // d(j, current)
+    f[2] = dgl_chain_dist(sq, p.x, p.y, nj, cx.xc, cx.yc, cx.nc);              // d(j, current)
     f[3] = a;
     f[4] = sd;
     f[5] = __fdiv_rn(__fsub_rn(cx.ys, p.y), den);
     f[6] = __fdiv_rn(__fsub_rn(cx.xs, p.x), den);
 }
 
-__device__ __forceinline__ void tsp_features(const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
-    tsp_row(cx, reinterpret_cast<const float2 *>(cx.xyb)[j], st.avg[cx.rowN + j], st.sd[cx.rowN + j], f);
+template <class SQ>
+__device__ __forceinline__ void tsp_features(const SQ &sq, const dgl_tsp_state_t &st, const TspRowCtx &cx, int j, float *f) {
+    tsp_row(sq, cx, reinterpret_cast<const float2 *>(cx.xyb)[j], st.avg[cx.rowN + j], st.sd[cx.rowN + j], f);
 }
 
 #define STEP_UNROLL 4     // node chunks (of 64) whose loads are issued together: bytes in flight per wave
@@ -64,10 +66,12 @@ struct TspBeamLink {
 // QUIET: the call takes part in every workgroup barrier but stores nothing to global memory (the spare wave pair of the
 // fused decode kernel's last workgroup when the row count is odd: a second in-place update of the same row would read
 // moments the first has already replaced).
-template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false, bool QUIET = false>
+// SQ: the square-root model (common.h).
+template <int WAVES, bool UPDATE, bool SPLIT = false, bool STREAM = false, bool QUIET = false, class SQ = DglSqrtIeee>
 __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const int32_t *__restrict__ selected, int t, int knn,
                                              int32_t *__restrict__ idx_out, float *__restrict__ tile_out, int lds_per_wave,
-                                             int mom_off, const TspBeamLink &link, float *lds, int r, int wave) {
+                                             int mom_off, const TspBeamLink &link, float *lds, int r, int wave,
+                                             const SQ &sq = SQ{}) {
     const int lane = threadIdx.x & 63;
     const int N = st.N, W = (N + 63) / 64;
     float *keys = lds + (SPLIT ? 0 : (size_t)wave * lds_per_wave);
@@ -144,8 +148,8 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
                 const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 float a1 = 0.0f, s1 = 0.0f;
                 if (UPDATE) {
-                    const float dcol = dgl_sqrt_pk(dgl_chain_sq(cross, nj, cx.nc));       // dis[j][cur]
-                    dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1);   // TSP/TSPEnv.py:386, 408-409
+                    const float dcol = sq.pk(dgl_chain_sq(cross, nj, cx.nc));             // dis[j][cur]
+                    dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1, sq);   // TSP/TSPEnv.py:386, 408-409
                     if (QUIET) {
                     } else if (STREAM) {
                         __builtin_nontemporal_store(a1, avg + j);
@@ -207,31 +211,31 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         const bool share = N >= 2048 && k <= 64;
         if (!share) {
             if (wave != 0 || QUIET) return;
-            c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+            c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj, SQ::ULPS);
         } else {
-            const float bound = __uint_as_float(wave_candidate_bound(lane_min, k));
+            const float bound = __uint_as_float(wave_candidate_bound(lane_min, k, SQ::ULPS));
             const int cw = wave_compact(keys, j_begin, j_end, bound, lists + 128 * wave,
                                         reinterpret_cast<int *>(lists + 128 * wave) + 64);
             if (lane == 0) counts[wave] = cw;
             __syncthreads();                                // `share` is uniform over the workgroup
             if (wave != 0 || QUIET) return;
-            c = wave_candidates_from_lists(lists, counts, WAVES, keys, N, k, bound, scratch, &ckey, &cj);
+            c = wave_candidates_from_lists(lists, counts, WAVES, keys, N, k, bound, scratch, &ckey, &cj, SQ::ULPS);
         }
     } else {
         if (QUIET) return;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj);
+        c = wave_candidates(keys, N, k, lane_min, scratch, &ckey, &cj, SQ::ULPS);
     }
     // more than 64 neighbours, row shared by the workgroup's waves: one pass with a bound from the scan classes' minima
     bool wide = false;
     if (SPLIT && c < 0 && k > 64 && k <= 256) {
         float *mins = scratch + 128;
-        wide = wave_select_wide<WAVES>(keys, N, k, mins, mins + 64 * WAVES, [&](int j, int rank) {
+        wide = wave_select_wide<WAVES>(sq, keys, N, k, mins, mins + 64 * WAVES, [&](int j, int rank) {
             idx_row[rank] = j;
-            tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+            tsp_features(sq, st, cx, j, tile + rank * DGL_TILE_STRIDE);
         });
-        if (wide && lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+        if (wide && lane == 63) tsp_features(sq, st, cx, cur, tile + k * DGL_TILE_STRIDE);
     }
     if (wide) {
     } else if (c >= 0) {
@@ -243,16 +247,16 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         float av, sv;
         if (mom) { const float2 m = mom[jl]; av = m.x; sv = m.y; } else { av = avg[jl]; sv = sd[jl]; }
         int rank;
-        const bool pick = wave_pick_k(dgl_sqrt(ckey), c, k, &rank);
+        const bool pick = wave_pick_k(sq(ckey), c, k, &rank);
         if (pick) idx_row[rank] = cj;
-        if (pick || anchor_early) tsp_row(cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
-        if (c == 64 && lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+        if (pick || anchor_early) tsp_row(sq, cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
+        if (c == 64 && lane == 63) tsp_features(sq, st, cx, cur, tile + k * DGL_TILE_STRIDE);
     } else {
-        wave_select_general(keys, N, k, scratch, [&](int j, int rank) {
+        wave_select_general(sq, keys, N, k, scratch, [&](int j, int rank) {
             idx_row[rank] = j;
-            tsp_features(st, cx, j, tile + rank * DGL_TILE_STRIDE);
+            tsp_features(sq, st, cx, j, tile + rank * DGL_TILE_STRIDE);
         });
-        if (lane == 63) tsp_features(st, cx, cur, tile + k * DGL_TILE_STRIDE);
+        if (lane == 63) tsp_features(sq, st, cx, cur, tile + k * DGL_TILE_STRIDE);
     }
     for (int e = k + lane; e < knn; e += 64) idx_row[e] = -1;
     wave_lds_sync();

@@ -1,0 +1,61 @@
+"""Which square root the state kernels reproduce (include/dgl_amd.h: dgl_set_sqrt_model).
+
+    "ieee"        correctly rounded roots (default)
+    "mkl_avx512"  what torch.sqrt / torch.cdist return on a CPU build of torch linked against MKL on an AVX-512 machine
+                  - the setting the golden vectors of this repository were captured under - together with the reset's
+                  means in torch.mean's own summation order: the device then carries the reference's state bit for bit.
+
+The setting is per device and process-wide; states reset after a change follow the new model."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+IEEE, MKL_AVX512 = 0, 1
+_TABLE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "rsqrt14_avx512.npz")
+_tables = {}          # device index -> the VRSQRT14 table on that device (kept alive while the library may read it)
+_current = {}         # device index -> model name
+
+
+def rsqrt14_table() -> np.ndarray:
+    """VRSQRT14 over [1, 4) as 2^24 uint16 (index = exponent parity << 23 | mantissa; value = (bits - 0x3F000000) >> 7,
+    the single entry 65536 - rsqrt14(1) = 1 - stored as 65535 and special-cased by its users)."""
+    z = np.load(_TABLE_FILE)
+    pos, val = z["pos"], z["val"]
+    table = np.repeat(val, np.diff(np.append(pos, 1 << 24)).astype(np.int64))
+    assert table.size == 1 << 24 and table.dtype == np.uint16
+    return table
+
+
+def use(model: str, device=None) -> None:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    lib = _lib.load()
+    with torch.cuda.device(index):
+        if model == "ieee":
+            _lib.check(lib.dgl_set_sqrt_model(IEEE, 0), "dgl_set_sqrt_model")
+        elif model == "mkl_avx512":
+            if index not in _tables:
+                _tables[index] = torch.from_numpy(rsqrt14_table().view(np.int16)).to(torch.device("cuda", index))
+            _lib.check(lib.dgl_set_sqrt_model(MKL_AVX512, _tables[index].data_ptr()), "dgl_set_sqrt_model")
+        else:
+            raise ValueError(f"square-root model {model!r}: expected 'ieee' or 'mkl_avx512'")
+    _current[index] = model
+
+
+def current(device=None) -> str:
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    return _current.get(index, "ieee")
+
+
+def apply(x: torch.Tensor) -> torch.Tensor:
+    """The current model's square root of a float32 device tensor (for checks against recorded torch.sqrt values)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dgl_sqrt_apply(x.data_ptr(), out.data_ptr(), x.numel(), _lib.stream_ptr()), "dgl_sqrt_apply")
+    return out

@@ -54,6 +54,27 @@ DGL_API int dgl_version(void);
 /* Thread-local, valid until the next failing call on the same thread. */
 DGL_API const char *dgl_last_error_string(void);
 
+/* ------------------------------------------------------- square-root model
+ * The reference's distances and running standard deviations come out of torch.cdist / torch.sqrt (TSP/TSPEnv.py:125,228,
+ * 408-409; CVRP/CVRPEnv.py:262,475,733-738), and on CPU torch hands contiguous float tensors to the math library it
+ * was built against.  With MKL on an AVX-512 machine - where this build's golden vectors were captured - that root is the
+ * instruction VRSQRT14's estimate refined once, which is one ulp below the correctly rounded root on 0.6 % of all
+ * inputs; the running standard deviations amplify such last-bit differences by N / #unvisited and the min-max
+ * normalisation by another hundredfold, so the last decisions of a tour can depend on them.  No counterpart in the
+ * reference's own interface: it selects which of the two the state kernels (reset, step, knn, state_data) reproduce.
+ *   DGL_SQRT_IEEE        correctly rounded roots (default; what torch without MKL, or on another CPU path, computes up
+ *                        to its own library's rounding); the reset's means are binary64 sums rounded once.
+ *   DGL_SQRT_MKL_AVX512  MKL's AVX-512 float sqrt bit for bit, and the reset's means in torch.mean's own summation
+ *                        order (8-lane cascade sum).  rsqrt14_table: VRSQRT14 over [1, 4) as 2^24 uint16 on the
+ *                        current device (dgl_amd/data/rsqrt14_avx512.npz expands to it), owned by the caller and kept
+ *                        alive while the model is set.  About 10 % slower state kernels.
+ * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to. */
+#define DGL_SQRT_IEEE 0
+#define DGL_SQRT_MKL_AVX512 1
+DGL_API int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table);
+/* out[i] = the model's square root of x[i] (for checking a model against recorded torch.sqrt values). */
+DGL_API int dgl_sqrt_apply(const float *x, float *out, int64_t n, dgl_stream_t stream);
+
 /* ------------------------------------------------------------------ TSP state
  * Compact per-row state that replaces the reference's Step_State
  * (TSP/TSPEnv.py:39-43: data [R,N,7], avg/std [R,N]) and its dense dis_matrix
