@@ -156,6 +156,8 @@ class TspEngine:
         self.knn = knn
         dev = torch.device("cuda", xy.device.index if xy.device.index is not None else torch.cuda.current_device())
         self.device = dev
+        from . import sqrt_model
+        sqrt_model.apply_environment(dev)
         R, N = self.R, self.N
         self.W = (N + 63) // 64
         self.bufs = [self._alloc_state() for _ in range(2 if rows_per_instance > 1 else 1)]   # 2nd copy: beam permutation target
@@ -397,6 +399,8 @@ class CvrpEngine:
         self.knn, self.depot_knn = knn, depot_knn
         dev = torch.device("cuda", xy.device.index if xy.device.index is not None else torch.cuda.current_device())
         self.device = dev
+        from . import sqrt_model
+        sqrt_model.apply_environment(dev)
         R = self.R
         self.W = (self.M + 63) // 64
         self.ntok_max = knn + depot_knn + 2

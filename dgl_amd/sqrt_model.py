@@ -47,6 +47,16 @@ def use(model: str, device=None) -> None:
     _current[index] = model
 
 
+def apply_environment(device) -> None:
+    """DGL_SQRT_MODEL=mkl_avx512 in the environment selects that model on every device an engine is created on (once
+    per device; an explicit ``use`` afterwards still wins)."""
+    index = torch.device(device).index
+    index = torch.cuda.current_device() if index is None else index
+    name = os.environ.get("DGL_SQRT_MODEL", "")
+    if name and index not in _current:
+        use(name, torch.device("cuda", index))
+
+
 def current(device=None) -> str:
     index = torch.cuda.current_device() if device is None else torch.device(device).index
     return _current.get(index, "ieee")

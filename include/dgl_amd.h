@@ -72,7 +72,8 @@ DGL_API const char *dgl_last_error_string(void);
 #define DGL_SQRT_IEEE 0
 #define DGL_SQRT_MKL_AVX512 1
 DGL_API int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table);
-/* out[i] = the model's square root of x[i] (for checking a model against recorded torch.sqrt values). */
+/* out[i] = the model's square root of x[i]: what torch.sqrt returns for x[i] under the model (the root the reference
+ * takes at TSP/TSPEnv.py:409 and CVRP/CVRPEnv.py:738), for checking a model against recorded torch.sqrt values. */
 DGL_API int dgl_sqrt_apply(const float *x, float *out, int64_t n, dgl_stream_t stream);
 
 /* ------------------------------------------------------------------ TSP state
