@@ -94,14 +94,26 @@ __device__ __forceinline__ float dgl_sqrt_pk(float x) {
 //                lanes look the estimate up.
 // sq(x): one root; sq.pk(x): the same value (the IEEE model evaluates its two residuals with one packed FMA there).
 // ULPS: how far above a bound on radicands a radicand can lie and still have a root that ties with the bound's.
-struct DglSqrtIeee {
+// DIRECT (instances of at most 25 points, see dgl_direct_sq): distance roots are the correctly rounded ones under
+// every model - torch.cdist takes them with the scalar sqrt there; sq.dist(x) / sq.dist_pk(x) are the roots of distance
+// radicands, sq(x) / sq.pk(x) those of the running variances.
+template <bool DIRECT_>
+struct DglSqrtIeeeT {
     static constexpr unsigned ULPS = 4u;
+    static constexpr bool DIRECT = DIRECT_;
     __device__ __forceinline__ float operator()(float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float pk(float x) const { return dgl_sqrt_pk(x); }
+    __device__ __forceinline__ float dist(float x) const { return dgl_sqrt(x); }
+    __device__ __forceinline__ float dist_pk(float x) const { return dgl_sqrt_pk(x); }
 };
-struct DglSqrtMkl {
+typedef DglSqrtIeeeT<false> DglSqrtIeee;
+template <bool DIRECT_>
+struct DglSqrtMklT {
     static constexpr unsigned ULPS = 8u;
+    static constexpr bool DIRECT = DIRECT_;
     const uint16_t *tab;
+    __device__ __forceinline__ float dist(float x) const { return DIRECT ? dgl_sqrt(x) : (*this)(x); }
+    __device__ __forceinline__ float dist_pk(float x) const { return dist(x); }
     __device__ __forceinline__ float operator()(float x) const {
         const float s0 = dgl_sqrt(x);
         const float ulp = __fsub_rn(s0, __uint_as_float(__float_as_uint(s0) - 1u));
@@ -121,6 +133,7 @@ struct DglSqrtMkl {
     }
     __device__ __forceinline__ float pk(float x) const { return (*this)(x); }
 };
+typedef DglSqrtMklT<false> DglSqrtMkl;
 
 // One node's running mean / standard deviation of its distances to the unvisited nodes when the node at distance
 // dcol leaves that set (TSP/TSPEnv.py:386,408-409; CVRP/CVRPEnv.py:711,733-738): up1 = u + 1, du = division by u,
@@ -157,9 +170,30 @@ __device__ __forceinline__ float dgl_chain_sq(float cross, float ni, float nj) {
 __device__ __forceinline__ float dgl_chain_dist(float xi, float yi, float ni, float xj, float yj, float nj) {
     return dgl_sqrt(dgl_chain_sq(dgl_chain_cross(xi, yi, xj, yj), ni, nj));
 }
+// Instances of at most 25 points: torch.cdist does not go through a matrix product there but evaluates
+//   d(i,j) = sqrt(fma(dy, dy, dx * dx)),  dx = x_i - x_j, dy = y_i - y_j   (a third coordinate: one more FMA)
+// per pair, with the correctly rounded scalar sqrt (checked bit for bit against torch.cdist for 20, 21 and 25 points):
+// symmetric, zero diagonal.  The kernels keep their structure (norms, cross term, sum, clamp, root) and switch the
+// pieces: with DIRECT the "norms" are 0 and the "cross term" is the whole squared distance, so dgl_chain_sq returns it
+// unchanged.
+#define DGL_DIRECT_MAX_POINTS 25
+__device__ __forceinline__ float dgl_direct_sq(float xi, float yi, float xj, float yj) {
+    const float dx = __fsub_rn(xi, xj), dy = __fsub_rn(yi, yj);
+    return __fmaf_rn(dy, dy, __fmul_rn(dx, dx));
+}
+template <bool DIRECT>
+__device__ __forceinline__ float dgl_sqnorm_t(float x, float y) { return DIRECT ? 0.0f : dgl_sqnorm(x, y); }
+template <bool DIRECT>
+__device__ __forceinline__ float dgl_cross_t(float xi, float yi, float xj, float yj) {
+    return DIRECT ? dgl_direct_sq(xi, yi, xj, yj) : dgl_chain_cross(xi, yi, xj, yj);
+}
+__device__ __forceinline__ float dgl_pair_dist(bool direct, float xi, float yi, float xj, float yj) {
+    return direct ? dgl_sqrt(dgl_direct_sq(xi, yi, xj, yj))
+                  : dgl_chain_dist(xi, yi, dgl_sqnorm(xi, yi), xj, yj, dgl_sqnorm(xj, yj));
+}
 template <class SQ>
 __device__ __forceinline__ float dgl_chain_dist(const SQ &sq, float xi, float yi, float ni, float xj, float yj, float nj) {
-    return sq(dgl_chain_sq(dgl_chain_cross(xi, yi, xj, yj), ni, nj));
+    return sq.dist(dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(xi, yi, xj, yj), ni, nj));
 }
 
 // v for the lanes whose bit is clear in the wave-uniform mask, +inf for the others: the mask

@@ -39,28 +39,40 @@ struct CvrpRowCtx {
 // D3: distances over (x, y, demand) as the training reset builds them (CVRP/CVRPEnv.py:519:
 // cdist over all three columns of the instance): |p|^2 = (x^2 + y^2) + z^2 and one more FMA in the
 // product chain.  The depot's demand is 0, so its products need no third term.
-template <bool D3>
+// DIRECT (at most 25 points, depot included: cdist's direct evaluation, common.h): the norms are 0 and the cross term is
+// the whole squared distance fma(dz, dz, fma(dy, dy, dx dx)) - the depot's third term then counts like any other.
+template <bool D3, bool DIRECT = false>
 __device__ __forceinline__ float cvrp_norm(float x, float y, float z) {
+    if (DIRECT) return 0.0f;
     const float n = dgl_sqnorm(x, y);
     return D3 ? __fadd_rn(n, __fmul_rn(z, z)) : n;
 }
-template <bool D3>
+template <bool D3, bool DIRECT = false>
 __device__ __forceinline__ float cvrp_cross(float xi, float yi, float zi, float xj, float yj, float zj) {
+    if (DIRECT) {
+        const float d2 = dgl_direct_sq(xi, yi, xj, yj), dz = __fsub_rn(zi, zj);
+        return D3 ? __fmaf_rn(dz, dz, d2) : d2;
+    }
     const float c = dgl_chain_cross(xi, yi, xj, yj);
     return D3 ? __fmaf_rn(-2.0f * zi, zj, c) : c;
+}
+// cross term against the depot (demand 0: the product chain needs no third term)
+template <bool D3, bool DIRECT>
+__device__ __forceinline__ float cvrp_cross_depot(float x, float y, float z, float x0, float y0) {
+    return DIRECT ? cvrp_cross<D3, true>(x, y, z, x0, y0, 0.0f) : dgl_chain_cross(x, y, x0, y0);
 }
 
 // raw data row of a node at p with demand dem and running statistics (a, sd)
 // (CVRP/CVRPEnv.py:696,718,746,782,801); returns d(j, depot)
 template <bool D3, class SQ>
 __device__ __forceinline__ float cvrp_row(const SQ &sq, const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
-    const float nj = cvrp_norm<D3>(p.x, p.y, dem);
-    const float d0 = dgl_chain_dist(sq, p.x, p.y, nj, cx.x0, cx.y0, cx.n0);    // d(j, depot)
+    const float nj = cvrp_norm<D3, SQ::DIRECT>(p.x, p.y, dem);
+    const float d0 = sq.dist(dgl_chain_sq(cvrp_cross_depot<D3, SQ::DIRECT>(p.x, p.y, dem, cx.x0, cx.y0), nj, cx.n0));   // d(j, depot)
     const float den = __fadd_rn(d0, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
     f[2] = dem;
-    f[3] = sq(dgl_chain_sq(cvrp_cross<D3>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
+    f[3] = sq.dist(dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
     f[4] = a;
     f[5] = sd;
     f[6] = __fdiv_rn(__fsub_rn(cx.y0, p.y), den);
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
     float cap = !UPDATE ? cap_old : (via ? __fsub_rn(1.0f, dem_cur) : __fsub_rn(cap_old, dem_cur));
     const float cap_eps = __fadd_rn(cap, 0.000001f);          // feasibility uses the un-nudged capacity
 
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = dem_cur; cx.nc = cvrp_norm<D3>(cx.xc, cx.yc, cx.zc);
-    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = dem_cur; cx.nc = cvrp_norm<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc);
+    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm_t<SQ::DIRECT>(cx.x0, cx.y0);
 
     const int u = M - t;                                       // CVRP/CVRPEnv.py:662 (>= 1: t <= N)
     const float up1 = (float)(u + 1);
@@ -177,10 +189,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             if (j < j_end) {
-                const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3>(x, y, g.dm[q]);
-                const float cross = cvrp_cross<D3>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
+                const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]);
+                const float cross = cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
                 if (UPDATE) {
-                    const float dcol = sq(dgl_chain_sq(cross, nj, cx.nc));                        // dis[j][cur]
+                    const float dcol = sq.dist(dgl_chain_sq(cross, nj, cx.nc));                       // dis[j][cur]
                     const float a0 = g.a0[q], s0 = g.s0[q];
                     const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);             // :711
                     const float e = __fsub_rn(dcol, a0);
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
                     if (chunk == (cur >> 6)) excl |= 1ull << (cur & 63);
                     if (chunk == 0) excl |= 1ull;
                     const float kl = dgl_inf_where(excl, dgl_chain_sq(cross, cx.nc, nj));
-                    const float kd = dgl_inf_where(excl, dgl_chain_sq(dgl_chain_cross(cx.x0, cx.y0, x, y), cx.n0, nj));
+                    const float kd = dgl_inf_where(excl, dgl_chain_sq(cvrp_cross_depot<D3, SQ::DIRECT>(x, y, g.dm[q], cx.x0, cx.y0), cx.n0, nj));
                     keysL[j] = kl;
                     keysD[j] = kd;
                     minL = fminf(minL, kl);
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(sq(ckey), c, kl, &rank);
+        const bool pick = wave_pick_k(sq.dist(ckey), c, kl, &rank);
         if (pick || anchor_early) {
             float *f = tileL + (pick ? rank : kl) * DGL_TILE_STRIDE;
             cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(sq(ckey), c, kd, &rank);
+        const bool pick = wave_pick_k(sq.dist(ckey), c, kd, &rank);
         if (pick || anchor_early) {
             float *f = tileD + (pick ? rank : kd) * DGL_TILE_STRIDE;
             const float d0 = cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
@@ -395,8 +407,8 @@ __global__ void cvrp_state_data_kernel(dgl_cvrp_state_t st, int t, float *__rest
     cx.demb = st.demand + (size_t)b * M;
     cx.rowM = (size_t)r * M;
     const int cur = st.nodes[(size_t)r * N + (t - 1)];
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = cx.demb[cur]; cx.nc = cvrp_norm<D3>(cx.xc, cx.yc, cx.zc);
-    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm(cx.x0, cx.y0);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.zc = cx.demb[cur]; cx.nc = cvrp_norm<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc);
+    cx.x0 = cx.xyb[0]; cx.y0 = cx.xyb[1]; cx.n0 = dgl_sqnorm_t<SQ::DIRECT>(cx.x0, cx.y0);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
         float f[CVRP_F];
         cvrp_features<D3>(sq, st, cx, j, f);
@@ -458,10 +470,6 @@ static int check_cvrp_state(const dgl_cvrp_state_t *st) {
     DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
     DGL_CHECK_ARG(st->xy && st->demand && st->avg && st->sd && st->capacity && st->visited && st->nodes && st->flags,
                   "NULL state buffer");
-    // (see check_tsp_state: torch.cdist's direct path for at most 25 points)
-    if (st->N + 1 <= 25)
-        return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points (depot included) are not supported "
-                             "(the reference's distance arithmetic differs there)", st->N);
     return DGL_OK;
 }
 
@@ -482,6 +490,25 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
         dgl_max_dynamic_lds((const void *)cvrp_reset_kernel, (int)lds);
     hipLaunchKernelGGL(cvrp_reset_kernel, dim3((M + 255) / 256, st->B), dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_cvrp_reset");
+    return DGL_OK;
+}
+
+// Instances of at most 25 points, depot included (torch.cdist's direct evaluation, common.h): one wave per row.
+template <bool UPDATE, bool D3, class SQ>
+static int launch_cvrp_step_small(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
+                                  int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
+                                  dgl_stream_t stream, const char *what, const CvrpBeamLink &link, SQ sq) {
+    static_assert(SQ::DIRECT, "the small-instance shape is the direct evaluation's");
+    const int M = st->N + 1;
+    const int per_wave = 2 * M + (knn + depot_knn + 2) * DGL_TILE_STRIDE + 128;
+    const size_t lds1 = (size_t)per_wave * sizeof(float);
+    DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d/%d need %zu bytes of LDS per row (max 153600)", st->N, knn,
+                  depot_knn, lds1);
+    if (lds1 > 48 * 1024)
+        dgl_max_dynamic_lds((const void *)cvrp_step_kernel<SQ, 1, UPDATE, D3>, (int)lds1);
+    hipLaunchKernelGGL((cvrp_step_kernel<SQ, 1, UPDATE, D3>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st, action,
+                       t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out, tile_out, per_wave, link, sq);
+    DGL_CHECK_LAUNCH(what);
     return DGL_OK;
 }
 
@@ -534,6 +561,13 @@ template <bool UPDATE, bool D3>
 static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, int32_t t, int32_t knn, int32_t depot_knn,
                             int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
                             dgl_stream_t stream, const char *what, const CvrpBeamLink &link = CvrpBeamLink{}) {
+    if (st->N + 1 <= DGL_DIRECT_MAX_POINTS) {
+        if (const uint16_t *tab = dgl_sqrt_table())
+            return launch_cvrp_step_small<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                                      tile_out, stream, what, link, DglSqrtMklT<true>{tab});
+        return launch_cvrp_step_small<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                                  tile_out, stream, what, link, DglSqrtIeeeT<true>{});
+    }
     if (const uint16_t *tab = dgl_sqrt_table())
         return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                                tile_out, stream, what, link, DglSqrtMkl{tab});
@@ -640,7 +674,12 @@ extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float 
         else
             hipLaunchKernelGGL((cvrp_state_data_kernel<false, SQ>), grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, sq);
     };
-    if (const uint16_t *tab = dgl_sqrt_table()) go(DglSqrtMkl{tab}); else go(DglSqrtIeee{});
+    const uint16_t *tab = dgl_sqrt_table();
+    if (st->N + 1 <= DGL_DIRECT_MAX_POINTS) {
+        if (tab) go(DglSqrtMklT<true>{tab}); else go(DglSqrtIeeeT<true>{});
+    } else {
+        if (tab) go(DglSqrtMkl{tab}); else go(DglSqrtIeee{});
+    }
     DGL_CHECK_LAUNCH("dgl_cvrp_state_data");
     return DGL_OK;
 }

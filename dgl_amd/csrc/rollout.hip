@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void tsp_decode_kernel(dgl_tsp_state_t st, con
 extern "C" int dgl_tsp_greedy_decode(const dgl_tsp_state_t *st, const float *packed_weights, const dgl_policy_io_t *io,
                                      int32_t t_done, int32_t t_end, int32_t knn, dgl_stream_t stream) {
     DGL_CHECK_ARG(st != nullptr && packed_weights != nullptr && io != nullptr, "NULL argument");
-    DGL_CHECK_ARG(st->B > 0 && st->N > 25 && st->rows_per_instance > 0 && st->R == st->B * st->rows_per_instance,
+    DGL_CHECK_ARG(st->B > 0 && st->N > 1 && st->rows_per_instance > 0 && st->R == st->B * st->rows_per_instance,
                   "bad sizes B=%d N=%d rows_per_instance=%d R=%d", st->B, st->N, st->rows_per_instance, st->R);
+    // the fused kernel's step phase implements the matrix-product distances of more than 25 points only (common.h,
+    // dgl_direct_sq): smaller instances take dgl_tsp_step + dgl_policy_forward
+    if (st->N <= DGL_DIRECT_MAX_POINTS)
+        return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: the fused decode takes instances of more than 25 points", st->N);
     DGL_CHECK_ARG(st->xy && st->avg && st->sd && st->visited && st->tour, "NULL state buffer");
     DGL_CHECK_ARG(t_done >= 1 && t_done <= t_end && t_end <= st->N, "steps [%d, %d) outside [1, N=%d]", t_done, t_end, st->N);
     DGL_CHECK_ARG(io->problem == DGL_PROBLEM_TSP && io->R == st->R && io->N == st->N, "io does not describe this state");

@@ -262,7 +262,7 @@ __device__ __forceinline__ bool wave_select_wide(const SQ &sq, const float *keys
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int s = 64 * q + lane;
-        root[q] = s < c ? sq(list[s]) : INFINITY;
+        root[q] = s < c ? sq.dist(list[s]) : INFINITY;
         cj[q] = s < c ? list_j[s] : 0;
         pick[q] = s < c;
     }
@@ -316,7 +316,7 @@ __device__ __forceinline__ bool wave_select_wide(const SQ &sq, const float *keys
 template <class SQ, class Emit>
 __device__ __forceinline__ void wave_select_general(const SQ &sq, float *keys, int n, int k, float *scratch, Emit emit) {
     const int lane = threadIdx.x & 63;
-    for (int j = lane; j < n; j += 64) keys[j] = sq(keys[j]);    // each lane roots the keys it wrote
+    for (int j = lane; j < n; j += 64) keys[j] = sq.dist(keys[j]);    // each lane roots the keys it wrote
     wave_lds_sync();
     const float T = wave_kth_smallest(keys, n, k, scratch);
     wave_emit_selected(keys, n, k, T, emit);

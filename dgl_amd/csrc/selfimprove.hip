@@ -24,6 +24,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // chosen, a move goes via the depot (flag 1, capacity refilled) when the load does not fit
 // (capacity + 1e-6 < demand), the first move always does.
 // dynamic LDS: float2 pts[M], float nrm[M] (|p|^2, -1 once visited).
+// M <= DGL_DIRECT_MAX_POINTS: cdist's direct evaluation (common.h, dgl_direct_sq); nrm then only marks the visited.
 template <bool CVRP>
 __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const float *__restrict__ xy,
                                                                        const float *__restrict__ demand, int M,
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const flo
     float *nrm = lds + 2 * (size_t)M;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float2 *in = reinterpret_cast<const float2 *>(xy) + (size_t)b * M;
+    const bool direct = M <= DGL_DIRECT_MAX_POINTS;
     for (int j = tid; j < M; j += NN_THREADS) {
         const float2 p = in[j];
         pts[j] = p;
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const flo
             const float nj = nrm[j];
             if (nj < 0.0f) continue;
             const float2 pj = pts[j];
-            const float d = dgl_chain_dist(pc.x, pc.y, nc, pj.x, pj.y, nj);
+            const float d = direct ? dgl_sqrt(dgl_direct_sq(pc.x, pc.y, pj.x, pj.y))
+                                   : dgl_chain_dist(pc.x, pc.y, nc, pj.x, pj.y, nj);
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
             best = key < best ? key : best;
         }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const flo
     }
     if (!CVRP && tid == 0) {
         const float2 pc = pts[cur], p0 = pts[0];               // closing edge: row = last node, column = node 0
-        total += (double)dgl_chain_dist(pc.x, pc.y, dgl_sqnorm(pc.x, pc.y), p0.x, p0.y, dgl_sqnorm(p0.x, p0.y));
+        total += (double)dgl_pair_dist(direct, pc.x, pc.y, p0.x, p0.y);
         length[b] = (float)total;
     }
 }
@@ -164,7 +167,6 @@ __global__ __launch_bounds__(256) void solution_augment_kernel(const int32_t *__
 extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, int32_t *solution, float *length,
                                          dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && solution && length && B > 0 && N > 1, "bad argument");
-    if (N <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)N * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
     dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<false>), (int)lds);
@@ -177,7 +179,6 @@ extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, 
 extern "C" int dgl_cvrp_nearest_neighbour(const float *xy, const float *demand, int32_t B, int32_t N, int32_t *nodes,
                                           int8_t *flags, dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && demand && nodes && flags && B > 0 && N > 0, "bad argument");
-    if (N + 1 <= 25) return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported", N);
     const size_t lds = (size_t)(N + 1) * 12;
     DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
     dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<true>), (int)lds);

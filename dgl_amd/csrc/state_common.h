@@ -10,10 +10,12 @@
 // the same j).  Also clears the visited bitmask.  z (may be NULL): a third coordinate per node
 // ([B][M]; the CVRP training reset measures distances over (x, y, demand), CVRP/CVRPEnv.py:519):
 // |p|^2 = (x^2 + y^2) + z^2 and the product chain gets one more FMA.
+// M <= DGL_DIRECT_MAX_POINTS: the direct evaluation (common.h, dgl_direct_sq; a third coordinate adds fma(dz, dz, .)).
 __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, const float *__restrict__ z, int M,
                                                int rows_per_instance,
                                                float *__restrict__ avg, float *__restrict__ sd,
                                                uint64_t *__restrict__ visited) {
+    const bool direct = M <= DGL_DIRECT_MAX_POINTS;
     extern __shared__ float lds_xy[];   // [M][2]
     const int b = blockIdx.y;
     const float *xyb = xy + (size_t)b * M * 2;
@@ -36,14 +38,16 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float2 pj = pts[j + e];
-                    const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
+                    const double d = (double)(direct ? dgl_sqrt(dgl_direct_sq(xi, yi, pj.x, pj.y))
+                                                     : dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y)));
                     s4[e] += d;
                     q4[e] = fma(d, d, q4[e]);
                 }
             }
             for (; j < M; ++j) {
                 const float2 pj = pts[j];
-                const double d = (double)dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y));
+                const double d = (double)(direct ? dgl_sqrt(dgl_direct_sq(xi, yi, pj.x, pj.y))
+                                                 : dgl_chain_dist(xi, yi, ni, pj.x, pj.y, dgl_sqnorm(pj.x, pj.y)));
                 s4[0] += d;
                 q4[0] = fma(d, d, q4[0]);
             }
@@ -54,6 +58,10 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, con
             auto dist3 = [&](int j) {
                 const float2 pj = pts[j];
                 const float zj = lds_z[j], nj = __fadd_rn(dgl_sqnorm(pj.x, pj.y), __fmul_rn(zj, zj));
+                if (direct) {
+                    const float dz = __fsub_rn(zi, zj);
+                    return (double)dgl_sqrt(__fmaf_rn(dz, dz, dgl_direct_sq(xi, yi, pj.x, pj.y)));
+                }
                 const float cross = __fmaf_rn(-2.0f * zi, zj, dgl_chain_cross(xi, yi, pj.x, pj.y));
                 return (double)dgl_sqrt(dgl_chain_sq(cross, ni, nj));
             };
@@ -120,8 +128,14 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
     const float2 *pts = reinterpret_cast<const float2 *>(lds_xy);
     const float xi = pts[ii].x, yi = pts[ii].y, zi = z ? lds_z[ii] : 0.0f;
     const float ni = z ? __fadd_rn(dgl_sqnorm(xi, yi), __fmul_rn(zi, zi)) : dgl_sqnorm(xi, yi);
+    const bool direct = M <= DGL_DIRECT_MAX_POINTS;            // (common.h, dgl_direct_sq: correctly rounded roots there)
     auto dist = [&](int j) {
         const float2 pj = pts[j];
+        if (direct) {
+            float d2 = dgl_direct_sq(xi, yi, pj.x, pj.y);
+            if (z) { const float dz = __fsub_rn(zi, lds_z[j]); d2 = __fmaf_rn(dz, dz, d2); }
+            return dgl_sqrt(d2);
+        }
         float cross = dgl_chain_cross(xi, yi, pj.x, pj.y), nj = dgl_sqnorm(pj.x, pj.y);
         if (z) {
             const float zj = lds_z[j];

@@ -45,8 +45,8 @@ __global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restri
     cx.xyb = st.xy + (size_t)(r / st.rows_per_instance) * N * 2;
     cx.rowN = (size_t)r * N;
     const int cur = st.tour[cx.rowN + (t - 1)], start = st.tour[cx.rowN];
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
-    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm_t<SQ::DIRECT>(cx.xc, cx.yc);
+    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm_t<SQ::DIRECT>(cx.xs, cx.ys);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) {
         float f[TSP_F];
         tsp_features(sq, st, cx, j, f);
@@ -116,11 +116,6 @@ static int check_tsp_state(const dgl_tsp_state_t *st) {
                   st->B, st->N, st->rows_per_instance);
     DGL_CHECK_ARG(st->R == st->B * st->rows_per_instance, "R=%d != B*rows_per_instance", st->R);
     DGL_CHECK_ARG(st->xy && st->avg && st->sd && st->visited && st->tour, "NULL state buffer");
-    // torch.cdist evaluates instances of at most 25 points with the direct formula sqrt(dx^2 + dy^2) instead of the
-    // matrix-product chain implemented here: results would differ from the reference's, so they are refused
-    if (st->N <= 25)
-        return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: instances of at most 25 points are not supported (the reference's "
-                             "distance arithmetic differs there)", st->N);
     return DGL_OK;
 }
 
@@ -141,6 +136,22 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     dim3 grid((st->N + 255) / 256, st->B);
     hipLaunchKernelGGL(tsp_reset_kernel, grid, dim3(256), lds, (hipStream_t)stream, *st);
     DGL_CHECK_LAUNCH("dgl_tsp_reset");
+    return DGL_OK;
+}
+
+// Instances of at most 25 points (torch.cdist's direct evaluation, common.h): one wave per row, one row per workgroup.
+template <bool UPDATE, class SQ>
+static int launch_tsp_step_small(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
+                                 float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link, SQ sq) {
+    static_assert(SQ::DIRECT, "the small-instance shape is the direct evaluation's");
+    const int per_wave = st->N + (knn + 1) * DGL_TILE_STRIDE + 128;
+    const size_t lds1 = (size_t)per_wave * sizeof(float);
+    DGL_CHECK_ARG(lds1 <= 150 * 1024, "N=%d, knn=%d need %zu bytes of LDS per row (max 153600)", st->N, knn, lds1);
+    if (lds1 > 48 * 1024)
+        dgl_max_dynamic_lds((const void *)tsp_step_kernel<SQ, 1, UPDATE>, (int)lds1);
+    hipLaunchKernelGGL((tsp_step_kernel<SQ, 1, UPDATE>), dim3(st->R), dim3(64), lds1, (hipStream_t)stream, *st,
+                       selected, t, knn, idx_out, tile_out, per_wave, 0, link, sq);
+    DGL_CHECK_LAUNCH(what);
     return DGL_OK;
 }
 
@@ -198,6 +209,11 @@ static int launch_tsp_step_sq(const dgl_tsp_state_t *st, const int32_t *selected
 template <bool UPDATE>
 static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
                            float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
+    if (st->N <= DGL_DIRECT_MAX_POINTS) {
+        if (const uint16_t *tab = dgl_sqrt_table())
+            return launch_tsp_step_small<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMklT<true>{tab});
+        return launch_tsp_step_small<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtIeeeT<true>{});
+    }
     if (const uint16_t *tab = dgl_sqrt_table())
         return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMkl{tab});
     return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtIeee{});
@@ -269,7 +285,12 @@ extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *d
     DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
     DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
     dim3 grid(min((st->N + 255) / 256, 64), st->R);
-    if (const uint16_t *tab = dgl_sqrt_table())
+    const uint16_t *tab = dgl_sqrt_table();
+    if (st->N <= DGL_DIRECT_MAX_POINTS && tab)
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMklT<true>>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMklT<true>{tab});
+    else if (st->N <= DGL_DIRECT_MAX_POINTS)
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtIeeeT<true>>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtIeeeT<true>{});
+    else if (tab)
         hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMkl>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMkl{tab});
     else
         hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtIeee>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtIeee{});

@@ -18,7 +18,7 @@ struct TspRowCtx {
 // sin/cos of the direction towards the start node (TSP/TSPEnv.py:371,393,415,430-475)
 template <class SQ>
 __device__ __forceinline__ void tsp_row(const SQ &sq, const TspRowCtx &cx, float2 p, float a, float sd, float *f) {
-    const float nj = dgl_sqnorm(p.x, p.y);
+    const float nj = dgl_sqnorm_t<SQ::DIRECT>(p.x, p.y);
     const float ds = dgl_chain_dist(sq, p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
     const float den = __fadd_rn(ds, 1e-7f);
     f[0] = p.x;
@@ -131,8 +131,8 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
     // (clamped: a node id outside [0, N) from a faulty caller must not turn into a wild address)
     const int cur = min(max(__builtin_amdgcn_readfirstlane(UPDATE ? selected[r] : st.tour[cx.rowN + (t - 1)]), 0), N - 1);
     const int start = (t == 1) ? cur : __builtin_amdgcn_readfirstlane(tour_in[0]);
-    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm(cx.xc, cx.yc);
-    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm(cx.xs, cx.ys);
+    cx.xc = cx.xyb[2 * cur]; cx.yc = cx.xyb[2 * cur + 1]; cx.nc = dgl_sqnorm_t<SQ::DIRECT>(cx.xc, cx.yc);
+    cx.xs = cx.xyb[2 * start]; cx.ys = cx.xyb[2 * start + 1]; cx.ns = dgl_sqnorm_t<SQ::DIRECT>(cx.xs, cx.ys);
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
     // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
     unsigned long long vis_words = 0;
@@ -144,11 +144,11 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             if (j < j_end) {
-                const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm(x, y);
-                const float cross = dgl_chain_cross(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
+                const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm_t<SQ::DIRECT>(x, y);
+                const float cross = dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 float a1 = 0.0f, s1 = 0.0f;
                 if (UPDATE) {
-                    const float dcol = sq.pk(dgl_chain_sq(cross, nj, cx.nc));             // dis[j][cur]
+                    const float dcol = sq.dist_pk(dgl_chain_sq(cross, nj, cx.nc));             // dis[j][cur]
                     dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1, sq);   // TSP/TSPEnv.py:386, 408-409
                     if (QUIET) {
                     } else if (STREAM) {
@@ -247,7 +247,7 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         float av, sv;
         if (mom) { const float2 m = mom[jl]; av = m.x; sv = m.y; } else { av = avg[jl]; sv = sd[jl]; }
         int rank;
-        const bool pick = wave_pick_k(sq(ckey), c, k, &rank);
+        const bool pick = wave_pick_k(sq.dist(ckey), c, k, &rank);
         if (pick) idx_row[rank] = cj;
         if (pick || anchor_early) tsp_row(sq, cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
         if (c == 64 && lane == 63) tsp_features(sq, st, cx, cur, tile + k * DGL_TILE_STRIDE);

@@ -297,6 +297,8 @@ class TspEngine:
         from . import sqrt_model
         if sqrt_model.current(self.device) != "ieee":          # the fused kernel's step phase takes correctly rounded roots
             return False
+        if self.N <= 25:                                       # ... and the matrix-product distances of more than 25 points
+            return False
         per_row = 4 * (self.N + (self.knn + 1) * TILE_STRIDE + 128 + 2 * 192 + 8 + 2 * self.N)
         return self.out_w == MAX_TOKENS and self.arithmetic == _lib.ARITH_SPLIT_F16 and 2 * per_row <= 150 * 1024
 

@@ -155,7 +155,7 @@ def cvrp_route_length(xy: Tensor, nodes: Tensor, flags: Tensor) -> Tensor:
 # TSP
 # --------------------------------------------------------------------------
 def chain_cdist(p: Tensor) -> Tensor:
-    """torch.cdist(p, p) for more than 25 points per instance, restated with elementwise IEEE operations so that the
+    """torch.cdist(p, p) restated for more than 25 points per instance with elementwise IEEE operations so that the
     result does not depend on which matrix-product kernel the BLAS library picks for this CPU and this size:
     [-2 p_i, |p_i|^2, 1] . [p_j, 1, |p_j|^2] accumulated left to right, first product rounded, every later term one
     fused multiply-add, then sqrt(max(., 0)).  binary32 FMAs are evaluated in binary64 (the product is exact there)
@@ -163,6 +163,14 @@ def chain_cdist(p: Tensor) -> Tensor:
     x, y, demand; CVRP/CVRPEnv.py:519).  In the container that generated the golden vectors this equals torch.cdist
     except where that build's vectorised float sqrt is 1 ulp off (about 0.6 % of the entries; tests/test_oracle_c.py)."""
     p = p.to(torch.float32)
+    if p.shape[1] <= 25:
+        # at most 25 points: ATen evaluates every pair directly, sqrt(fma(dz, dz, fma(dy, dy, dx dx))) with the scalar
+        # (correctly rounded) sqrt: symmetric, zero diagonal
+        d = p[:, :, None, :] - p[:, None, :, :]
+        acc = d[..., 0] * d[..., 0]
+        for c in range(1, p.shape[-1]):
+            acc = (d[..., c].double() * d[..., c].double() + acc.double()).float()
+        return acc.double().sqrt().float()
     sq = p * p
     n = sq[..., 0] + sq[..., 1]
     for c in range(2, p.shape[-1]):

@@ -15,7 +15,9 @@
  *         acc  = fl(acc + n_i)
  *         acc  = fl(acc + n_j)
  *         d_ij = sqrt(max(acc, 0))
- *     (asymmetric, non-zero diagonal).  Checked bit-for-bit against torch.cdist in
+ *     (asymmetric, non-zero diagonal).  For at most 25 points ATen evaluates every pair directly:
+ *         d_ij = sqrt(fma(dy, dy, fl(dx * dx))),  dx = x_i - x_j, dy = y_i - y_j
+ *     (symmetric, zero diagonal).  Both checked bit-for-bit against torch.cdist in
  *     tests/test_oracle_c.py.
  *   - row mean / population std of that matrix (TSP/TSPEnv.py:234-235), accumulated in
  *     double and rounded once (torch sums the mean in float with a cascade order that
@@ -48,12 +50,19 @@ static inline float chain_dist(float xi, float yi, float ni, float xj, float yj,
     return sqrtf(acc > 0.0f ? acc : 0.0f);
 }
 
+/* the per-pair form cdist takes for at most DIRECT_MAX_POINTS points */
+#define DIRECT_MAX_POINTS 25
+static inline float direct_dist(float xi, float yi, float xj, float yj) {
+    float dx = xi - xj, dy = yi - yj;
+    return sqrtf(fmaf(dy, dy, dx * dx));
+}
+
 /* out[j] = d(i, j), j = 0..n-1 (row i of the matrix) */
 DGLREF_API void dglref_dist_row(const float *xy, int n, int i, float *out) {
     float xi = xy[2 * i], yi = xy[2 * i + 1], ni = sqnorm(xi, yi);
     for (int j = 0; j < n; ++j) {
         float xj = xy[2 * j], yj = xy[2 * j + 1];
-        out[j] = chain_dist(xi, yi, ni, xj, yj, sqnorm(xj, yj));
+        out[j] = n <= DIRECT_MAX_POINTS ? direct_dist(xi, yi, xj, yj) : chain_dist(xi, yi, ni, xj, yj, sqnorm(xj, yj));
     }
 }
 
@@ -62,7 +71,7 @@ DGLREF_API void dglref_dist_col(const float *xy, int n, int c, float *out) {
     float xc = xy[2 * c], yc = xy[2 * c + 1], nc = sqnorm(xc, yc);
     for (int j = 0; j < n; ++j) {
         float xj = xy[2 * j], yj = xy[2 * j + 1];
-        out[j] = chain_dist(xj, yj, sqnorm(xj, yj), xc, yc, nc);
+        out[j] = n <= DIRECT_MAX_POINTS ? direct_dist(xj, yj, xc, yc) : chain_dist(xj, yj, sqnorm(xj, yj), xc, yc, nc);
     }
 }
 

@@ -364,6 +364,13 @@ TRAINED_CASES = {
     # more than 32 tokens per row: the CVRPLIB setting (CVRP/test_cvrplib.py:326-327) and a TSP row of 51 tokens
     "cvrp_n200_b4_k50_nn": ("cvrp", dict(seed=321, B=4, N=200, knn=50, depot_knn=50)),
     "tsp_n200_b4_k50_nn": ("tsp", dict(seed=321, B=4, N=200, knn=50)),
+    # at most 25 points per instance: torch.cdist evaluates the distances pair by pair instead of through a matrix
+    # product (20 customers + depot = 21 points; 24 + 1 = 25 is the last size on that path, 25 + 1 the first beyond it)
+    "tsp_n20_b64_nn": ("tsp", dict(seed=2020, B=64, N=20, knn=30)),
+    "tsp_n25_b64_nn_tours": ("tsp", dict(seed=2025, B=64, N=25, knn=10, light="tours")),
+    "cvrp_n20_b64_nn": ("cvrp", dict(seed=2020, B=64, N=20, knn=15, depot_knn=15)),
+    "cvrp_n24_b64_nn_tours": ("cvrp", dict(seed=2024, B=64, N=24, knn=8, depot_knn=8, light="tours")),
+    "cvrp_n25_b64_nn_tours": ("cvrp", dict(seed=2025, B=64, N=25, knn=8, depot_knn=8, light="tours")),
 }
 
 CASES = {
@@ -380,6 +387,11 @@ CASES = {
     "cvrp_n1000_b2": ("cvrp", dict(seed=123, B=2, N=1000, knn=15, depot_knn=15, snap_steps=(1, 500))),
     "cvrp_n60_b2_beam4_pomo2": ("cvrp", dict(seed=789, B=2, N=60, knn=15, depot_knn=15, beam=4, pomo=2)),
     "cvrp_n120_b2_k20": ("cvrp", dict(seed=5, B=2, N=120, knn=20, depot_knn=20)),
+    # at most 25 points: cdist's pair-by-pair evaluation (see the trained cases)
+    "tsp_n20_b4": ("tsp", dict(seed=20, B=4, N=20, knn=30, full=True, snap_steps=(1, 2, 10, 19))),
+    "tsp_n25_b2_beam4": ("tsp", dict(seed=25, B=2, N=25, knn=10, beam=4)),
+    "cvrp_n20_b4": ("cvrp", dict(seed=20, B=4, N=20, knn=15, depot_knn=15, full=True, snap_steps=(1, 2, 10, 19))),
+    "cvrp_n24_b2_beam4": ("cvrp", dict(seed=24, B=2, N=24, knn=8, depot_knn=8, beam=4)),
 }
 
 

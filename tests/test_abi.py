@@ -45,20 +45,18 @@ def test_every_entry_point_cites_the_reference():
         assert re.search(r"\.py:\d+", comment), f"{name} has no reference file:line citation"
 
 
-def test_instances_of_at_most_25_points_are_refused():
-    """torch.cdist takes its direct sqrt(dx^2 + dy^2) path for at most 25 points; the kernels implement the
-    matrix-product arithmetic only, so such instances are refused before anything is launched."""
+def test_fused_decode_refuses_instances_of_at_most_25_points():
+    """torch.cdist evaluates at most 25 points pair by pair; the step, reset and nearest-neighbour kernels follow it
+    there (tests/test_gpu_small.py), the fused decode kernel implements the matrix-product distances only and
+    refuses such instances before anything is launched."""
     import ctypes
     from dgl_amd import _lib
     lib = _lib.load()
     fake = 4096                                   # never dereferenced: the size check comes first
-    st = _lib.TspState(2, 20, 1, 2, fake, fake, fake, fake, fake)
-    assert lib.dgl_tsp_reset(ctypes.byref(st), None) == -2                  # DGL_ERR_UNSUPPORTED
+    st = _lib.TspState(2, 25, 1, 2, fake, fake, fake, fake, fake)
+    io = _lib.PolicyIO()
+    assert lib.dgl_tsp_greedy_decode(ctypes.byref(st), fake, ctypes.byref(io), 1, 25, 10, None) == -2   # DGL_ERR_UNSUPPORTED
     assert b"25 points" in lib.dgl_last_error_string()
-    cv = _lib.CvrpState(2, 20, 1, 2, fake, fake, fake, fake, fake, fake, fake, fake, 0)      # 21 points with the depot
-    assert lib.dgl_cvrp_reset(ctypes.byref(cv), None) == -2
-    assert lib.dgl_tsp_nearest_neighbour(fake, 2, 25, fake, fake, None) == -2
-    assert lib.dgl_cvrp_nearest_neighbour(fake, fake, 2, 24, fake, fake, None) == -2
 
 
 def test_general_path_refuses_bad_token_counts_and_misaligned_workspace():

@@ -36,7 +36,8 @@ def _setup(name, device):
 
 @pytest.mark.parametrize("name", ["tsp_n60_b2_beam4_pomo2", "tsp_n200_b1_beam16", "tsp_n200_b2_beam8_nn",
                                   "cvrp_n60_b2_beam4_pomo2", "cvrp_n150_b2_beam8_nn",
-                                  "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn"])
+                                  "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn",
+                                  "tsp_n25_b2_beam4", "cvrp_n24_b2_beam4"])
 def test_teacher_forced_beam_steps(name, device):
     """At every step: dense and compact kernels agree with each other and with the reference's
     (scores, prev_k, action); the state is then advanced with the reference's own choice.

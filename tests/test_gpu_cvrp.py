@@ -24,7 +24,7 @@ def _actions(case):
     return case["nodes"].astype(np.int32) + (N + 1) * case["flags"].astype(np.int32)
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20", "cvrp_n20_b4"])
 def test_reset_matches_golden(name, device):
     case, _ = load_golden(name)
     eng = _engine(case, device)
@@ -35,7 +35,7 @@ def test_reset_matches_golden(name, device):
 
 
 @pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n100_b64_nn", "cvrp_n120_b2_k20",
-                                  "cvrp_n200_b4_k50_nn"])
+                                  "cvrp_n200_b4_k50_nn", "cvrp_n20_b4", "cvrp_n20_b64_nn"])
 def test_teacher_forced_steps_match_golden(name, device):
     """Drive the state with the reference's own route; at every step: both index sets bit-exact, capacities
     bit-exact, logits within 1e-3 of the row's largest |logit| while more than 8 nodes are left, and for ALL steps
@@ -125,7 +125,7 @@ def test_teacher_forced_steps_match_golden(name, device):
         assert max_exact_col_err < 2e-5
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n20_b4"])
 def test_state_data_matches_golden(name, device):
     case, _ = load_golden(name)
     eng = _engine(case, device)
@@ -202,7 +202,9 @@ def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
                                                 ("cvrp_n100_b256_nn_tours", 0.99),
                                                 ("cvrp_n1000_b128_nn_tours", 0.99),
                                                 ("cvrp_n1000_b512_nn_tours", 0.97),
-                                                ("cvrp_n1000_b128_clustered_nn_tours", 0.8)])
+                                                ("cvrp_n1000_b128_clustered_nn_tours", 0.8),
+                                                ("cvrp_n20_b64_nn", 0.98), ("cvrp_n24_b64_nn_tours", 0.98),
+                                                ("cvrp_n25_b64_nn_tours", 0.98)])
 def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
     """Greedy routes against the reference's own, trained checkpoint.  The 512-instance population of the headline
     size is held to 97 % against the reference's run and to 99 % against the second opinion its fixture carries

@@ -31,7 +31,7 @@ def test_square_roots_bit_for_bit(device, mkl):
     assert np.array_equal(mkl.apply(x).cpu().numpy().view(np.uint32), ieee.view(np.uint32))
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n1000_b128_nn_tours"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n1000_b128_nn_tours", "tsp_n20_b4"])
 def test_tsp_reset_moments_bit_for_bit(name, device, mkl):
     from dgl_amd.engine import TspEngine
     case, _ = load_golden(name)
@@ -41,7 +41,7 @@ def test_tsp_reset_moments_bit_for_bit(name, device, mkl):
     assert np.array_equal(eng.state["sd"].cpu().numpy(), case["std0"])
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n1000_b128_nn_tours"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n1000_b128_nn_tours", "cvrp_n20_b4"])
 def test_cvrp_reset_moments_bit_for_bit(name, device, mkl):
     from test_gpu_cvrp import _engine
     case, _ = load_golden(name)
@@ -51,7 +51,7 @@ def test_cvrp_reset_moments_bit_for_bit(name, device, mkl):
     assert np.array_equal(eng.state["sd"].cpu().numpy(), case["std0"])
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n20_b4"])
 def test_tsp_state_bit_for_bit_along_the_reference_tour(name, device, mkl):
     """Driven with the reference's own tour: the dense state (coordinates, distance to the current node, running mean and
     standard deviation, directions) equals the reference's snapshots bit for bit, down to the last steps of the tour,
@@ -115,7 +115,7 @@ def test_cvrp_population_routes_under_the_references_square_roots(name, min_iden
     assert same.mean() >= min_identical
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n1000_b2", "cvrp_n20_b4"])
 def test_cvrp_state_bit_for_bit_along_the_reference_route(name, device, mkl):
     """The CVRP counterpart: dense state snapshots (and capacities) along the reference's own route, and the normalised
     token tiles of both neighbourhoods where the fixture holds them, bit for bit."""

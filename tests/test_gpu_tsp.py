@@ -15,7 +15,7 @@ def _engine(case, device, knn=None, rpi=1):
     return TspEngine(xy, rpi, int(case["meta/knn"]) if knn is None else knn)
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n20_b4"])
 def test_reset_matches_golden(name, device):
     case, _ = load_golden(name)
     eng = _engine(case, device)
@@ -26,7 +26,8 @@ def test_reset_matches_golden(name, device):
     np.testing.assert_allclose(sd, case["std0"], rtol=3e-7, atol=0)
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn", "tsp_n200_b4_k50_nn"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn", "tsp_n200_b4_k50_nn",
+                                  "tsp_n20_b4", "tsp_n20_b64_nn"])
 def test_teacher_forced_steps_match_golden(name, device):
     """Drive the state with the reference's own tour; at every step compare the kNN index
     sets (bit-exact), the normalised token tile and the logits (1e-3 relative)."""
@@ -80,7 +81,7 @@ def test_teacher_forced_steps_match_golden(name, device):
         assert max_tile_err < 5e-3
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n20_b4"])
 def test_state_data_matches_golden(name, device):
     case, _ = load_golden(name)
     eng = _engine(case, device)
@@ -100,7 +101,7 @@ def test_state_data_matches_golden(name, device):
             np.testing.assert_allclose(data[:, :, 5:], g[:, :, 5:], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2"])
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n20_b4"])
 def test_greedy_rollout_length(name, device):
     from dgl_amd.engine import PackedPolicy
     from dgl_amd._lib import PROBLEM_TSP
@@ -124,7 +125,8 @@ def test_greedy_rollout_length(name, device):
                                                 ("tsp_n100_b512_nn_tours", 0.99),
                                                 ("tsp_n1000_b128_nn_tours", 0.99),
                                                 ("tsp_n1000_b512_nn_tours", 0.99),
-                                                ("tsp_n1000_b128_clustered_nn_tours", 0.9)])
+                                                ("tsp_n1000_b128_clustered_nn_tours", 0.9),
+                                                ("tsp_n20_b64_nn", 0.98), ("tsp_n25_b64_nn_tours", 0.98)])
 def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     """With the trained checkpoint fixture (peaked action distributions) the greedy tours must be
     the reference's own: >= 99 % of instances on the populations (512 instances of 100 nodes, 128 instances of

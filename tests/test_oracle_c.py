@@ -37,7 +37,24 @@ def test_chain_distance_is_cdist_matmul_path(lib, N):
     assert (cd != want).mean() < 0.02
 
 
-@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn"])
+@pytest.mark.parametrize("N", [2, 5, 20, 25])
+def test_direct_distance_is_cdist_for_at_most_25_points(lib, N):
+    """At most 25 points: torch.cdist evaluates every pair as sqrt(fma(dy, dy, dx dx)) with the scalar sqrt; the C
+    restatement equals it bit for bit (rows and columns: the matrix is symmetric there)."""
+    torch.manual_seed(N)
+    x = torch.rand(8, N, 2)
+    cd = torch.cdist(x, x).numpy()
+    row, col = np.empty(N, np.float32), np.empty(N, np.float32)
+    for bi in range(8):
+        xy = np.ascontiguousarray(x[bi].numpy())
+        for i in range(N):
+            lib.dglref_dist_row(xy, N, i, row)
+            lib.dglref_dist_col(xy, N, i, col)
+            assert np.array_equal(row, cd[bi, i])
+            assert np.array_equal(col, cd[bi, :, i])
+
+
+@pytest.mark.parametrize("name", ["tsp_n50_b4", "tsp_n100_b8", "tsp_n1000_b2", "tsp_n100_b64_nn", "tsp_n20_b4", "tsp_n20_b64_nn"])
 def test_tsp_knn_sets_match_reference(lib, name):
     case, _ = load_golden(name)
     xy, tour, knn = case["xy"], case["tour"], int(case["meta/knn"])
@@ -58,7 +75,7 @@ def test_tsp_knn_sets_match_reference(lib, name):
     assert bad == 0
 
 
-@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20"])
+@pytest.mark.parametrize("name", ["cvrp_n60_b4", "cvrp_n100_b8", "cvrp_n120_b2_k20", "cvrp_n20_b4"])
 def test_cvrp_knn_sets_match_reference(lib, name):
     import ctypes
     case, _ = load_golden(name)
