@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DGL_AMD_LIB", os.path.join(_HERE, "lib", "libdgl_amd.
 
 TILE_STRIDE = 12
 MAX_TOKENS = 32
+MAX_WIDE_TOKENS = 128
 STATIC_WORKSPACE_FLOATS = 16 * 1024 * 1024   # DGL_STATIC_WORKSPACE_FLOATS
 PROBLEM_TSP = 0
 PROBLEM_CVRP = 1

@@ -470,12 +470,18 @@ static int launch_policy(const float *P, const dgl_policy_io_t *io, hipStream_t 
 
 extern "C" int dgl_policy_forward(const float *packed_weights, const dgl_policy_io_t *io, dgl_stream_t stream) {
     DGL_CHECK_ARG(packed_weights != nullptr, "packed_weights is NULL");
-    if (int e = check_io(io)) return e;
+    const bool wide = io != nullptr && io->n > DGL_MAX_TOKENS;
+    if (int e = check_io(io, wide && io->arithmetic == DGL_ARITH_SPLIT_F16 ? DGL_MAX_WIDE_TOKENS : DGL_MAX_TOKENS)) return e;
     DGL_CHECK_ARG(io->tile != nullptr, "tile is NULL");
-    DGL_CHECK_ARG(io->out_stride == 0 || io->out_stride == DGL_MAX_TOKENS, "the fused kernels write %d floats per row",
-                  DGL_MAX_TOKENS);
     DGL_CHECK_ARG(io->tile_row_stride >= io->n * DGL_TILE_STRIDE, "tile_row_stride %d < n*%d", io->tile_row_stride,
                   DGL_TILE_STRIDE);
+    if (wide) {
+        // 33..128 tokens per row, split-f16 arithmetic: one workgroup per row (policy16_wide.h)
+        DGL_CHECK_ARG(io->out_stride >= io->n, "out_stride %d < n=%d tokens per row", io->out_stride, io->n);
+        return dgl_launch_policy16_wide(packed_weights, io, (hipStream_t)stream);
+    }
+    DGL_CHECK_ARG(io->out_stride == 0 || io->out_stride == DGL_MAX_TOKENS, "the 32-token kernels write %d floats per row",
+                  DGL_MAX_TOKENS);
     // two rows per workgroup share every weight fragment; a single row per workgroup
     // keeps all 256 CUs busy when there are few rows
     if (io->arithmetic == DGL_ARITH_SPLIT_F16) return dgl_launch_policy16(packed_weights, io, (hipStream_t)stream);

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "policy16_body.h"
+#include "policy16_wide.h"
 
 template <int ROWS, int GROUPS = 1>
 __global__ __launch_bounds__(256 * GROUPS) void policy_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
@@ -48,6 +49,33 @@ static int launch16(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
     hipLaunchKernelGGL((policy_kernel_f16<ROWS, GROUPS>), dim3((io->R + per_wg - 1) / per_wg), dim3(256 * GROUPS), lds, s, P, *io);
     DGL_CHECK_LAUNCH("dgl_policy_forward");
     return DGL_OK;
+}
+
+// rows of 33..128 tokens: one workgroup per row (policy16_wide.h)
+template <int NT>
+__global__ __launch_bounds__(256) void policy_wide_kernel_f16(const float *__restrict__ P, dgl_policy_io_t io) {
+    extern __shared__ float lds[];
+    policy16_wide<NT>(P, io, lds, blockIdx.x);
+}
+
+template <int NT>
+static int launch_wide(const float *P, const dgl_policy_io_t *io, hipStream_t s) {
+    const size_t lds = policy16_wide_lds_bytes<NT>();
+    static_assert(policy16_wide_lds_bytes<NT>() <= 160 * 1024, "a row's images must fit a workgroup's LDS");
+    dgl_max_dynamic_lds((const void *)policy_wide_kernel_f16<NT>, (int)lds);
+    hipLaunchKernelGGL((policy_wide_kernel_f16<NT>), dim3(io->R), dim3(256), lds, s, P, *io);
+    DGL_CHECK_LAUNCH("dgl_policy_forward");
+    return DGL_OK;
+}
+
+int dgl_launch_policy16_wide(const float *packed, const dgl_policy_io_t *io, hipStream_t stream) {
+    const int nt = (io->n + 31) / 32;
+    switch (nt) {
+    case 2: return launch_wide<2>(packed, io, stream);
+    case 3:
+    case 4: return launch_wide<4>(packed, io, stream);
+    default: return dgl_set_error(DGL_ERR_UNSUPPORTED, "n=%d tokens per row: the one-launch kernels take 2..%d", io->n, DGL_MAX_WIDE_TOKENS);
+    }
 }
 
 int dgl_launch_policy16(const float *packed, const dgl_policy_io_t *io, hipStream_t stream) {

@@ -85,7 +85,13 @@ __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float
 // BASE: position of the GEMM's first fragment in the wave's stream, modulo the ring depth.
 // PASSES = 2 leaves the weights' low halves out (W rounded to binary16, the activation still split): an experiment
 // switch for single GEMMs (DGL_W2_PASSES), the stream is consumed the same way.
-template <int ROWS, int ARRS, int BASE, int PASSES = 3>
+// FENCE: every K-step's matrix instructions stay where they are written.  Matrix instructions have no side effects, so
+// in a kernel whose accumulators are read much later the compiler may sink a whole product's instructions past the next
+// product's loads - keeping every operand fragment of both alive, far more than the register file holds.  An empty
+// assembly statement that "updates" the accumulators after each step (no instruction is emitted) ties them to their
+// place; a compiler-level memory fence does the same for the loads.
+__device__ __forceinline__ void pin_acc(f32x16 &acc) { asm volatile("" : "+a"(acc)); }
+template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = false>
 __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                          f32x16 (&acc)[ROWS]) {
     // activation operands are read one K-step ahead of the MFMAs that consume them
@@ -97,6 +103,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
     }
     Unroll<0, 8>::run([&](auto ss) {
         constexpr int s = decltype(ss)::value;
+        if constexpr (FENCE) asm volatile("" ::: "memory");
         const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
         const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
         f16x8 xh[ROWS], xl[ROWS];
@@ -115,6 +122,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
             if constexpr (PASSES == 3) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
             acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
             acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+            if constexpr (FENCE) pin_acc(acc[rr]);
         }
     });
 }
@@ -124,7 +132,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
 // 4-cycle VALU instructions written between two MFMAs cost nothing.  side(step, row, part) is called
 // after MFMA `part` (0..2) of `row` in K-step `step` and must not depend on acc; scheduling barriers
 // pin the written order.
-template <int ROWS, int ARRS, int BASE, int PASSES = 3, class Side>
+template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = false, class Side>
 __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                               f32x16 (&acc)[ROWS], Side side) {
     f16x8 nh[ROWS], nl[ROWS];
@@ -135,6 +143,7 @@ __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Flo
     }
     Unroll<0, 8>::run([&](auto ss) {
         constexpr int s = decltype(ss)::value;
+        if constexpr (FENCE) asm volatile("" ::: "memory");
         const f16x8 wh = as_h8(ring.template take<(BASE + 2 * s) % PF16>());
         const f16x8 wl = as_h8(ring.template take<(BASE + 2 * s + 1) % PF16>());
         f16x8 xh[ROWS], xl[ROWS];
@@ -155,6 +164,7 @@ __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Flo
                 if constexpr (part == 0 && PASSES == 3) acc[rr] = MFMA16(wl, xh[rr], acc[rr]);
                 if constexpr (part == 1) acc[rr] = MFMA16(wh, xl[rr], acc[rr]);
                 if constexpr (part == 2) acc[rr] = MFMA16(wh, xh[rr], acc[rr]);
+                if constexpr (FENCE) pin_acc(acc[rr]);
                 __builtin_amdgcn_sched_barrier(0);
                 side(ss, rc, pp);
             });

@@ -132,3 +132,4 @@ __device__ __forceinline__ void policy_row_output(const dgl_policy_io_t &io, int
 
 // defined in policy16.hip
 int dgl_launch_policy16(const float *packed, const dgl_policy_io_t *io, hipStream_t stream);
+int dgl_launch_policy16_wide(const float *packed, const dgl_policy_io_t *io, hipStream_t stream);   // 33..DGL_MAX_WIDE_TOKENS tokens

@@ -99,9 +99,18 @@ def general_workspace(engine, R: int, n: int) -> torch.Tensor:
     return ws
 
 
+def wide_forward_enabled() -> bool:
+    """Rows of 33..128 tokens in one launch (dgl_policy_forward's wide kernels); DGL_WIDE_FORWARD=0 sends them through
+    the general path's sequence of launches instead (A/B measurements)."""
+    return os.environ.get("DGL_WIDE_FORWARD", "1") != "0"
+
+
 def policy_forward(engine, policy: PackedPolicy, io: _lib.PolicyIO) -> None:
-    """The fused kernels for rows of at most 32 tokens, the general path otherwise."""
+    """The one-launch kernels for rows of at most 32 tokens, and of 33..128 tokens under the split-f16 arithmetic; the
+    general path otherwise."""
     if engine.out_w == MAX_TOKENS:
+        check(engine.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+    elif (MAX_TOKENS < io.n <= _lib.MAX_WIDE_TOKENS and engine.arithmetic == _lib.ARITH_SPLIT_F16 and wide_forward_enabled()):
         check(engine.lib.dgl_policy_forward(ptr(policy.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
     else:
         ws = general_workspace(engine, io.R, io.n)
@@ -134,7 +143,7 @@ def forward_range_guarded(engine, policy: "PackedPolicy") -> None:
     when the split-f16 kernel reports an operand at the edge of the binary16 range."""
     engine.overflow.zero_()
     engine.forward(policy)
-    if engine.arithmetic == _lib.ARITH_SPLIT_F16 and engine.out_w == MAX_TOKENS and int(engine.overflow.item()) != 0:
+    if engine.arithmetic == _lib.ARITH_SPLIT_F16 and int(engine.overflow.item()) != 0:
         engine.arithmetic = _lib.ARITH_F32
         try:
             engine.forward(policy)

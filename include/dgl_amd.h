@@ -40,7 +40,8 @@ extern "C" {
 #define DGL_ERR_LAUNCH (-3)
 
 #define DGL_TILE_STRIDE 12 /* floats per token in a feature tile (7 used for TSP, 9 for CVRP) */
-#define DGL_MAX_TOKENS 32  /* tokens per row handled by dgl_policy_forward */
+#define DGL_MAX_TOKENS 32  /* tokens per row of the 32-token kernels of dgl_policy_forward (and its default row width) */
+#define DGL_MAX_WIDE_TOKENS 128 /* tokens per row dgl_policy_forward takes under DGL_ARITH_SPLIT_F16 (one workgroup per row) */
 
 #if defined(__GNUC__)
 #define DGL_API __attribute__((visibility("default")))
@@ -231,7 +232,9 @@ DGL_API int dgl_policy_pack(const dgl_policy_weights_t *w, float *packed, dgl_st
 /* TSPModel.forward / CVRPModel.forward after the tile is built (TSP/TSPModel.py:257-339,
  * CVRP/CVRPModel.py:397-523): logits, masked softmax, small-probability floor, greedy pick.
  *  tile: row r starts at tile + r*tile_row_stride, n tokens of DGL_TILE_STRIDE floats each;
- *  n <= DGL_MAX_TOKENS tokens per row.
+ *  n <= DGL_MAX_TOKENS tokens per row; under DGL_ARITH_SPLIT_F16 also DGL_MAX_TOKENS < n <= DGL_MAX_WIDE_TOKENS
+ *  (neighbourhoods of 50 + 50 nodes, CVRP/test_cvrplib.py:326-327): then out_stride >= n is required and the
+ *  outputs have out_stride floats per row.  More tokens, or such rows under DGL_ARITH_F32: dgl_policy_general.
  *  TSP : tokens 0..n-2 candidates, token n-1 = current node (anchor 0).
  *  CVRP: tokens 0..kl-1 direct candidates, kl = anchor 0 (current node),
  *        kl+1..n-2 via-depot candidates, n-1 = anchor 1 (depot).

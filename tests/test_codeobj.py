@@ -14,7 +14,8 @@ import pytest
 LIB = os.path.join(os.path.dirname(__file__), "..", "dgl_amd", "lib", "libdgl_amd.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # every function the split's inline assembly is compiled into
-ASM_SPLIT_USERS = ("policy_kernel_f16ILi1ELi1EE", "policy_kernel_f16ILi2ELi1EE", "decode_policy_phase")
+ASM_SPLIT_USERS = ("policy_kernel_f16ILi1ELi1EE", "policy_kernel_f16ILi2ELi1EE", "decode_policy_phase",
+                   "policy_wide_kernel_f16ILi2EE", "policy_wide_kernel_f16ILi4EE")
 
 
 @pytest.fixture(scope="module")
@@ -62,3 +63,18 @@ def test_vgpr_form_kernels_do_not_use_the_inline_asm(disassembly):
         mfma_v = [l for l in body if "v_mfma_" in l and not l.split("v_mfma_")[1].split()[1].startswith("a")]
         if mfma_v:
             assert not any("v_fma_mix_f32" in l for l in body), f"{n}: VGPR-form matrix results beside the inline-assembly split"
+
+
+def test_wide_policy_kernels_fit_the_instruction_cache_and_do_not_spill(disassembly):
+    """The kernels for rows of 33..128 tokens (policy16_wide.h): one block of the network is a loop body that has to fit
+    the 64 KB instruction cache (as unrolled code it did not, and every pass was fetched from memory), and its products
+    are pinned so that the register allocator has no operand fragments of several products to keep alive - a build
+    that spills to scratch memory stalls a wave that has its SIMD to itself for a full memory round trip per reload."""
+    for nt, spill_limit in ((2, 0), (4, 8)):
+        names = [n for n in disassembly if f"policy_wide_kernel_f16ILi{nt}EE" in n]
+        assert names
+        body = disassembly[names[0]]
+        insts = [l for l in body if re.match(r"^\s+[sv]_|^\s+(ds|global|scratch|buffer)_", l)]
+        scratch = [l for l in body if "scratch_" in l]
+        assert len(scratch) <= spill_limit, f"{names[0]}: {len(scratch)} scratch accesses"
+        assert len(insts) * 8 < 80 * 1024, f"{names[0]}: about {len(insts) * 8 // 1024} KB of code"

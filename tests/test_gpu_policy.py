@@ -177,3 +177,76 @@ def test_range_guard_sees_weights_beyond_binary16(device):
     ref.arithmetic = _lib.ARITH_F32
     ref.reset(); ref.step(start); ref.forward(pol)
     assert torch.equal(sel, ref.selected)
+
+
+def _wide_vs_general(eng, pol, n_cols):
+    """One evaluation through dgl_policy_forward's wide kernel and one through the general path's launches."""
+    import ctypes
+    from dgl_amd._lib import check, ptr, stream_ptr
+    from dgl_amd.engine import general_workspace
+    outs = []
+    for wide in (True, False):
+        eng.logits.zero_(); eng.prob.zero_(); eng.selected.zero_()
+        io = eng.policy_io()
+        if wide:
+            check(eng.lib.dgl_policy_forward(ptr(pol.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+        else:
+            ws = general_workspace(eng, io.R, io.n)
+            check(eng.lib.dgl_policy_general(ctypes.byref(pol.w), None, ctypes.byref(io), 0, 0.0, ptr(ws), 0, stream_ptr()),
+                  "dgl_policy_general")
+        torch.cuda.synchronize()
+        outs.append((eng.logits[:, :n_cols].cpu().numpy().copy(), eng.prob[:, :n_cols].cpu().numpy().copy(),
+                     eng.selected.cpu().numpy().copy()))
+    return outs
+
+
+@pytest.mark.parametrize("knn", [32, 50, 63, 64, 70, 95, 96, 100, 127])      # 33 .. 128 tokens: 2, 3 and 4 tiles, full and ragged
+@pytest.mark.parametrize("weights", ["random", "trained"])
+def test_tsp_wide_kernel_agrees_with_general_path(knn, weights, device):
+    """Rows of 33..128 tokens in one launch (one workgroup per row, policy16_wide.h) against the general path's
+    sequence of kernels: two f32-accurate evaluations of the same network (TSP/TSPModel.py:238-457)."""
+    import os
+    from conftest import GOLDEN
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy
+    from dgl_amd.weights import load_checkpoint, random_state_dict
+    sd = random_state_dict("TSP", 3) if weights == "random" else load_checkpoint(os.path.join(GOLDEN, "ckpt_tsp_nn.pt"))
+    eng = _tsp_engine(37, 300, knn, device, seed=knn)
+    pol = PackedPolicy(sd, _lib.PROBLEM_TSP, device)
+    assert eng.overflow.item() == 0
+    (la, pa, sa), (lb, pb, sb) = _wide_vs_general(eng, pol, knn + 1)
+    scale = np.abs(lb).max(axis=1, keepdims=True)
+    rel = float((np.abs(la - lb) / scale).max())
+    print(f"knn={knn} {weights}: max relative logit difference wide kernel vs general path {rel:.2e}")
+    assert rel < 3e-5
+    np.testing.assert_allclose(pa, pb, rtol=5e-4, atol=1e-7)
+    assert (sa == sb).mean() >= 0.97 and eng.overflow.item() == 0
+
+
+@pytest.mark.parametrize("knn,kd", [(16, 16), (30, 30), (50, 50), (40, 63), (63, 63)])
+def test_cvrp_wide_kernel_agrees_with_general_path(knn, kd, device):
+    """The CVRP token layout (direct candidates, current node, via-depot candidates, depot; two anchors re-embedded at
+    the decoder's entry, infeasible direct moves masked: CVRP/CVRPModel.py:407-523) through the wide kernel."""
+    import os
+    from conftest import GOLDEN
+    from dgl_amd import _lib
+    from dgl_amd.engine import CvrpEngine, PackedPolicy
+    from dgl_amd.weights import load_checkpoint
+    g = torch.Generator().manual_seed(knn + kd)
+    R, N = 29, 200
+    xy = torch.rand(R, N + 1, 2, generator=g)
+    dem = torch.cat((torch.zeros(R, 1), torch.randint(1, 200, (R, N), generator=g) / 500.0), 1)
+    eng = CvrpEngine(xy.to(device), dem.to(device), 1, knn, kd)
+    eng.reset()
+    eng.step((torch.randint(1, N + 1, (R,), generator=g, dtype=torch.int32) + N + 1).to(device))
+    eng.step(torch.randint(1, N + 1, (R,), generator=g, dtype=torch.int32).to(device))
+    pol = PackedPolicy(load_checkpoint(os.path.join(GOLDEN, "ckpt_cvrp_nn.pt")), _lib.PROBLEM_CVRP, device)
+    n = eng.policy_io().n
+    assert n == knn + kd + 2
+    (la, pa, sa), (lb, pb, sb) = _wide_vs_general(eng, pol, n)
+    scale = np.abs(lb).max(axis=1, keepdims=True)
+    rel = float((np.abs(la - lb) / scale).max())
+    print(f"knn={knn}/{kd}: max relative logit difference wide kernel vs general path {rel:.2e}")
+    assert rel < 3e-5
+    np.testing.assert_allclose(pa, pb, rtol=5e-4, atol=1e-7)
+    assert (sa == sb).mean() >= 0.97
