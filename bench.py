@@ -23,7 +23,8 @@ kernel on the same tiles; ``roofline_knn`` the HBM-bound state-update + kNN + ti
 the workload's batch and at a batch large enough to fill the chip; ``measured_peaks`` what this
 card delivers for a float4 triad / copy and for back-to-back matrix instructions on random
 operands; ``tsp10000_beam16`` and ``cvrp5000_train`` are BASELINE.json's configurations 4 and 5 on one GPU (a beam-16
-decode of TSP-10000 instances; a training decode step of the CVRP policy at knn = depot_knn = 100 on CVRP-5000 rows).
+decode of TSP-10000 instances; a training decode step of the CVRP policy at knn = depot_knn = 100 on CVRP-5000 rows);
+``cvrplib_k50_forward`` one policy evaluation on rows of 102 tokens (the CVRPLIB neighbourhoods, knn = depot_knn = 50).
 ``cpu_baseline`` is the oracle (the PyTorch-CPU restatement of the reference path) on a
 bounded sample.
 """
@@ -344,6 +345,7 @@ def main():
             out["reference_bits_mode"] = bench_reference_bits_mode(args, dev)
             out["tsp10000_beam16"] = bench_tsp10000_beam(dev)
             out["cvrp5000_train"] = bench_cvrp5000_train(dev)
+            out["cvrplib_k50_forward"] = bench_wide_forward(dev)
             out["measured_peaks"] = mp = measured_peaks(dev)
             for o in (out, out.get(f"cvrp{args.nodes}")):
                 if o:
@@ -454,6 +456,53 @@ def bench_tsp10000_beam(dev, beam: int = 16, instances: int = 32, N: int = 10000
             "step_kernel": {"avg_launch_ms": ms_step, "bytes_per_launch": by, "achieved": by / (ms_step * 1e-3) / 1e9,
                             "unit": "GB/s", "frac": by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, "rows": R, "nodes": N,
                             "note": "greedy-form step (in-place update) timed with an event pair per launch"}}
+
+
+def bench_wide_forward(dev, rows: int = 512, N: int = 1000, k: int = 50, iters: int = 20):
+    """One policy evaluation on rows of 2 k + 2 = 102 tokens, the neighbourhoods the reference solves the CVRPLIB
+    instances with (CVRP/test_cvrplib.py:326-327: knn = depot_knn = 50): dgl_policy_forward's one-launch kernel for
+    33..128 tokens, and the general path's sequence of launches on the same tiles beside it."""
+    import ctypes
+    from dgl_amd._lib import PROBLEM_CVRP, check, ptr, stream_ptr
+    from dgl_amd.engine import CvrpEngine, PackedPolicy, general_workspace
+    from dgl_amd.weights import random_state_dict
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(rows, N + 1, 2, generator=g).to(dev)
+    dem = torch.cat((torch.zeros(rows, 1), torch.randint(1, 200, (rows, N), generator=g) / 500.0), 1).to(dev)
+    eng = CvrpEngine(xy, dem, 1, k, k)
+    pol = PackedPolicy(random_state_dict("CVRP", 1), PROBLEM_CVRP, dev)
+    eng.reset()
+    eng.step(torch.full((rows,), 5 + 2 + N, dtype=torch.int32, device=dev))
+    io = eng.policy_io(want_logits=False, want_prob=False)
+    ws = general_workspace(eng, io.R, io.n)
+
+    def wide():
+        check(eng.lib.dgl_policy_forward(ptr(pol.packed), ctypes.byref(io), stream_ptr()), "dgl_policy_forward")
+
+    def general():
+        check(eng.lib.dgl_policy_general(ctypes.byref(pol.w), None, ctypes.byref(io), 0, 0.0, ptr(ws), 0, stream_ptr()),
+              "dgl_policy_general")
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    n = io.n
+    flops = rows * policy_flops_per_row(n, 9, 2)
+    ms_wide, ms_general = timed(wide), timed(general)
+    return {"metric": "us per policy forward, rows of 102 tokens", "value": ms_wide * 1e3, "unit": "us", "higher_is_better": False,
+            "rows": rows, "tokens_per_row": n, "achieved": flops / ms_wide / 1e9, "unit_achieved": "TFLOP/s (algorithmic)",
+            "frac": flops / ms_wide / 1e9 / PEAK_F16_MATRIX_TFLOPS,
+            "general_path_us": ms_general * 1e3,
+            "config": {"workload": f"CVRP policy forward, {rows} rows x {n} tokens (knn = depot_knn = {k}), random-init weights"}}
 
 
 def bench_cvrp5000_train(dev, rows: int = 64, N: int = 5000, knn: int = 100, iters: int = 20):

@@ -28,6 +28,9 @@ __device__ __forceinline__ f16x8 as_h8(f32x4 v) { return __builtin_bit_cast(f16x
 #ifndef DGL_RANGE_GUARD
 #define DGL_RANGE_GUARD 1
 #endif
+#ifndef DGL_PIN_PRODUCTS
+#define DGL_PIN_PRODUCTS 0                   // 1: the 32-token kernel's products are pinned as well (see gemm16_t, FENCE)
+#endif
 __device__ __forceinline__ void track_range(float a, float b, float &mx) {
 #if DGL_RANGE_GUARD
     mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), __builtin_fabsf(b));
@@ -91,7 +94,7 @@ __device__ __forceinline__ void store_split(const f32x16 &x, _Float16 *H, _Float
 // assembly statement that "updates" the accumulators after each step (no instruction is emitted) ties them to their
 // place; a compiler-level memory fence does the same for the loads.
 __device__ __forceinline__ void pin_acc(f32x16 &acc) { asm volatile("" : "+a"(acc)); }
-template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = false>
+template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = (DGL_PIN_PRODUCTS != 0)>
 __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                          f32x16 (&acc)[ROWS]) {
     // activation operands are read one K-step ahead of the MFMAs that consume them
@@ -132,7 +135,7 @@ __device__ __forceinline__ void gemm16_t(WeightRing<PF16> &ring, const _Float16 
 // 4-cycle VALU instructions written between two MFMAs cost nothing.  side(step, row, part) is called
 // after MFMA `part` (0..2) of `row` in K-step `step` and must not depend on acc; scheduling barriers
 // pin the written order.
-template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = false, class Side>
+template <int ROWS, int ARRS, int BASE, int PASSES = 3, bool FENCE = (DGL_PIN_PRODUCTS != 0), class Side>
 __device__ __forceinline__ void gemm16_t_with(WeightRing<PF16> &ring, const _Float16 *H, const _Float16 *L,
                                               f32x16 (&acc)[ROWS], Side side) {
     f16x8 nh[ROWS], nl[ROWS];
@@ -359,6 +362,9 @@ __device__ __forceinline__ void policy16_rows(const float *__restrict__ P, const
                     av[rr] = MFMA16(xh[rr], vl, av[rr]);
                     av[rr] = MFMA16(xl[rr], vh, av[rr]);
                     av[rr] = MFMA16(xh[rr], vh, av[rr]);
+#if DGL_PIN_PRODUCTS
+                    pin_acc(aq[rr]); pin_acc(ak[rr]); pin_acc(av[rr]);
+#endif
                 }
             });
         }

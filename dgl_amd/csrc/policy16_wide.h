@@ -419,9 +419,13 @@ __device__ __forceinline__ void policy16_wide(const float *__restrict__ P, const
                         s[kt] = MFMA16(kh[hd][kt], ql, s[kt]);
                         s[kt] = MFMA16(kh[hd][kt], qh, s[kt]);
                     }
+                    // padded keys: rows of this kernel have more than 16 NT tokens, so only the upper half of the tiles
+                    // can hold any (a real branch per tile: the statement in it keeps the compiler from turning it
+                    // into sixteen selects that every row would execute)
 #pragma unroll
-                    for (int kt = 1; kt < NT; ++kt) {
-                        if (n < 32 * (kt + 1)) {                 // wave-uniform: a tile with padded keys (or nothing else)
+                    for (int kt = NT / 2; kt < NT; ++kt) {
+                        if (n < 32 * (kt + 1)) {                 // wave-uniform
+                            asm volatile("");
 #pragma unroll
                             for (int m = 0; m < 16; ++m) {
                                 const int j = 32 * kt + (m & 3) + 8 * (m >> 2) + 4 * h;
