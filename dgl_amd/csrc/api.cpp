@@ -64,7 +64,7 @@ extern "C" int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table) 
     if (model != DGL_SQRT_IEEE && model != DGL_SQRT_MKL_AVX512)
         return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "unknown square-root model %d", model);
     if (model == DGL_SQRT_MKL_AVX512 && rsqrt14_table == nullptr)
-        return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "DGL_SQRT_MKL_AVX512 needs the VRSQRT14 table (2^24 uint16 on this device)");
+        return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "DGL_SQRT_MKL_AVX512 needs the VRSQRT14 table (2^16 uint16 on this device)");
     std::lock_guard<std::mutex> lock(g_sqrt_mutex);
     g_sqrt_table[device] = model == DGL_SQRT_MKL_AVX512 ? rsqrt14_table : nullptr;
     return DGL_OK;

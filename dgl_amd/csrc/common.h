@@ -88,8 +88,11 @@ __device__ __forceinline__ float dgl_sqrt_pk(float x) {
 //                (where the golden vectors were captured): MKL's vector sqrt refines the instruction VRSQRT14's estimate
 //                y once, s = x y, result = fma(fma(-s, s, x), y / 2, s), which is the correctly rounded root or - on
 //                0.6 % of all inputs, whenever the exact root lies less than 0.06 ulp above the midpoint of two floats -
-//                the float below it.  `tab` holds VRSQRT14 over [1, 4): 2^24 entries of 16 bits, index = exponent
-//                parity << 23 | mantissa (tools/make_rsqrt14_table.py; the estimate scales exactly with the exponent).
+//                the float below it.  `tab` holds VRSQRT14 over [1, 4): the instruction's estimate depends on the
+//                exponent's parity and the upper 15 mantissa bits only (measured over all 2^24 inputs of [1, 4),
+//                tools/make_rsqrt14_table.py), so the table has 2^16 entries of 16 bits, index = parity << 15 |
+//                mantissa >> 8 (128 KB: L2-resident); the exact powers of 4 are special-cased (estimate exactly 1);
+//                the estimate scales exactly with the exponent.
 //                Only inputs whose correctly rounded root was rounded up by more than 0.4 ulp can differ, so only those
 //                lanes look the estimate up.
 // sq(x): one root; sq.pk(x): the same value (the IEEE model evaluates its two residuals with one packed FMA there).
@@ -101,6 +104,7 @@ template <bool DIRECT_>
 struct DglSqrtIeeeT {
     static constexpr unsigned ULPS = 4u;
     static constexpr bool DIRECT = DIRECT_;
+    static constexpr bool BATCHED = false;      // roots are taken one at a time where they are needed
     __device__ __forceinline__ float operator()(float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float pk(float x) const { return dgl_sqrt_pk(x); }
     __device__ __forceinline__ float dist(float x) const { return dgl_sqrt(x); }
@@ -111,7 +115,52 @@ template <bool DIRECT_>
 struct DglSqrtMklT {
     static constexpr unsigned ULPS = 8u;
     static constexpr bool DIRECT = DIRECT_;
+    // The scan loops take the roots of a whole group of node chunks together (roots<K>): the table look-ups of the K
+    // roots are then K loads in flight behind ONE wave-uniform branch instead of K dependent round trips (nearly
+    // every wave has some lane that needs the table: one input in ten passes the filter).
+    static constexpr bool BATCHED = true;
     const uint16_t *tab;
+    // the filter: the exact root lies more than 0.4 ulp below the correctly rounded one
+    __device__ __forceinline__ static bool needs_table(float x, float s0) {
+        const float ulp = __fsub_rn(s0, __uint_as_float(__float_as_uint(s0) - 1u));
+        return __fmaf_rn(-s0, s0, x) < -0.8f * __fmul_rn(s0, ulp);
+    }
+    __device__ __forceinline__ static unsigned table_index(float x) {
+        const unsigned b = __float_as_uint(x);
+        const int e = (int)(b >> 23) - 127, p = e & 1;
+        return ((unsigned)p << 23) | (b & 0x7FFFFFu);
+    }
+    __device__ __forceinline__ static float refined(float x, unsigned i, unsigned t) {
+        const int e = (int)(__float_as_uint(x) >> 23) - 127, p = e & 1, q = (e - p) >> 1;
+        unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + (t << 7);
+        yb -= (unsigned)q << 23;
+        const float y = __uint_as_float(yb);
+        const float s = __fmul_rn(x, y), h = __fmul_rn(0.5f, y);
+        return __fmaf_rn(__fmaf_rn(-s, s, x), h, s);
+    }
+    // out[k] = the model's root of x[k], k < K (distance roots under DIRECT: the correctly rounded ones)
+    template <int K>
+    __device__ __forceinline__ void roots(const float (&x)[K], float (&out)[K], bool distance) const {
+        bool need[K];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            out[k] = dgl_sqrt(x[k]);
+            need[k] = !(DIRECT && distance) && needs_table(x[k], out[k]);
+            any = any || need[k];
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+            unsigned idx[K], t[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                idx[k] = need[k] ? table_index(x[k]) : 0u;      // (the others read entry 0: one shared line)
+                t[k] = tab[idx[k] >> 8];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (need[k]) out[k] = refined(x[k], idx[k], t[k]);
+        }
+    }
     __device__ __forceinline__ float dist(float x) const { return DIRECT ? dgl_sqrt(x) : (*this)(x); }
     __device__ __forceinline__ float dist_pk(float x) const { return dist(x); }
     __device__ __forceinline__ float operator()(float x) const {
@@ -123,7 +172,7 @@ struct DglSqrtMklT {
             const unsigned b = __float_as_uint(x);
             const int e = (int)(b >> 23) - 127, p = e & 1, q = (e - p) >> 1;
             const unsigned i = ((unsigned)p << 23) | (b & 0x7FFFFFu);
-            unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + ((unsigned)tab[i] << 7);
+            unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + ((unsigned)tab[i >> 8] << 7);
             yb -= (unsigned)q << 23;
             const float y = __uint_as_float(yb);
             const float s = __fmul_rn(x, y), h = __fmul_rn(0.5f, y);
@@ -139,6 +188,20 @@ typedef DglSqrtMklT<false> DglSqrtMkl;
 // dcol leaves that set (TSP/TSPEnv.py:386,408-409; CVRP/CVRPEnv.py:711,733-738): up1 = u + 1, du = division by u,
 //   avg' = (avg up1 - dcol) / u,   sd' = sqrt((sd^2 up1 - (dcol - avg)^2) / u)   (CLAMP: radicand < 0 -> 0).
 // The same roundings as the scalar formulas, with the two numerators and the two divisions in packed instructions.
+// the same without the final root: *item = the radicand of sd'
+template <bool CLAMP>
+__device__ __forceinline__ void dgl_update_moments_item(float dcol, float a0, float s0, float up1, const DglConstDiv &du,
+                                                        float *a1, float *item_out) {
+    const float e = __fsub_rn(dcol, a0);
+    const dgl_f2 num = dgl_f2{a0, __fmul_rn(s0, s0)} * dgl_splat2(up1) - dgl_f2{dcol, __fmul_rn(e, e)};
+    const dgl_f2 q = num * dgl_splat2(du.rb);
+    const dgl_f2 rem = dgl_fma2(-q, dgl_splat2(du.b), num);
+    const dgl_f2 res = dgl_fma2(rem, dgl_splat2(du.rb), q);
+    float item = res.y;
+    if (CLAMP && item < 0.0f) item = 0.0f;
+    *a1 = res.x;
+    *item_out = item;
+}
 template <bool CLAMP, class SQ = DglSqrtIeee>
 __device__ __forceinline__ void dgl_update_moments(float dcol, float a0, float s0, float up1, const DglConstDiv &du,
                                                    float *a1, float *s1, const SQ &sq = SQ{}) {

@@ -185,13 +185,37 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        // models that take their roots in batches (common.h, BATCHED): both roots of all chunks of the group first
+        float a1b[STEP_UNROLL], s1b[STEP_UNROLL];
+        if constexpr (SQ::BATCHED && UPDATE) {
+            float rad[STEP_UNROLL], dcolb[STEP_UNROLL], item[STEP_UNROLL];
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                rad[q] = dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]),
+                                      cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]), cx.nc);
+            }
+            sq.roots(rad, dcolb, true);
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float a0 = g.a0[q], s0 = g.s0[q], dcol = dcolb[q];
+                a1b[q] = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);                          // :711
+                const float e = __fsub_rn(dcol, a0);
+                float it = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
+                item[q] = it < 0.0f ? 0.0f : it;                                                     // :735-736
+            }
+            sq.roots(item, s1b, false);
+        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]);
                 const float cross = cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
-                if (UPDATE) {
+                if constexpr (SQ::BATCHED && UPDATE) {
+                    avg[j] = a1b[q];
+                    sd[j] = s1b[q];
+                } else if (UPDATE) {
                     const float dcol = sq.dist(dgl_chain_sq(cross, nj, cx.nc));                       // dis[j][cur]
                     const float a0 = g.a0[q], s0 = g.s0[q];
                     const float a1 = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);             // :711

@@ -140,6 +140,21 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        // models that take their roots in batches (common.h, BATCHED): both roots of all chunks of the group first
+        float a1b[STEP_UNROLL], s1b[STEP_UNROLL];
+        if constexpr (SQ::BATCHED && UPDATE) {
+            float rad[STEP_UNROLL], dcolb[STEP_UNROLL], item[STEP_UNROLL];
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                rad[q] = dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y), dgl_sqnorm_t<SQ::DIRECT>(x, y), cx.nc);
+            }
+            sq.roots(rad, dcolb, true);
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q)
+                dgl_update_moments_item<false>(dcolb[q], g.a0[q], g.s0[q], up1, du, &a1b[q], &item[q]);
+            sq.roots(item, s1b, false);
+        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
@@ -147,7 +162,18 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
                 const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm_t<SQ::DIRECT>(x, y);
                 const float cross = dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 float a1 = 0.0f, s1 = 0.0f;
-                if (UPDATE) {
+                if constexpr (SQ::BATCHED && UPDATE) {
+                    a1 = a1b[q];
+                    s1 = s1b[q];
+                    if (QUIET) {
+                    } else if (STREAM) {
+                        __builtin_nontemporal_store(a1, avg + j);
+                        __builtin_nontemporal_store(s1, sd + j);
+                    } else {
+                        avg[j] = a1;
+                        sd[j] = s1;
+                    }
+                } else if (UPDATE) {
                     const float dcol = sq.dist_pk(dgl_chain_sq(cross, nj, cx.nc));             // dis[j][cur]
                     dgl_update_moments<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1, &s1, sq);   // TSP/TSPEnv.py:386, 408-409
                     if (QUIET) {

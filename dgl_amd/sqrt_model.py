@@ -21,7 +21,7 @@ _tables = {}          # device index -> the VRSQRT14 table on that device (kept 
 _current = {}         # device index -> model name
 
 
-def rsqrt14_table() -> np.ndarray:
+def rsqrt14_table_full() -> np.ndarray:
     """VRSQRT14 over [1, 4) as 2^24 uint16 (index = exponent parity << 23 | mantissa; value = (bits - 0x3F000000) >> 7,
     the single entry 65536 - rsqrt14(1) = 1 - stored as 65535 and special-cased by its users)."""
     z = np.load(_TABLE_FILE)
@@ -29,6 +29,19 @@ def rsqrt14_table() -> np.ndarray:
     table = np.repeat(val, np.diff(np.append(pos, 1 << 24)).astype(np.int64))
     assert table.size == 1 << 24 and table.dtype == np.uint16
     return table
+
+
+def rsqrt14_table() -> np.ndarray:
+    """The table the library takes (dgl_set_sqrt_model): 2^16 uint16, index = exponent parity << 15 | mantissa >> 8.
+    The instruction's estimate is constant over every block of 256 consecutive inputs except for the exact powers of 4
+    (input index 0, estimate exactly 1: special-cased by the kernels), which the assertion below re-checks on the
+    recorded data."""
+    full = rsqrt14_table_full()
+    blocks = full.reshape(1 << 16, 256)
+    compact = blocks[:, 1].copy()
+    same = blocks[:, 1:] == compact[:, None]
+    assert same.all() and (blocks[1:, 0] == compact[1:]).all(), "VRSQRT14 varies inside a block of 256 inputs"
+    return compact
 
 
 def use(model: str, device=None) -> None:

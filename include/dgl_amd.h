@@ -66,9 +66,11 @@ DGL_API const char *dgl_last_error_string(void);
  *   DGL_SQRT_IEEE        correctly rounded roots (default; what torch without MKL, or on another CPU path, computes up
  *                        to its own library's rounding); the reset's means are binary64 sums rounded once.
  *   DGL_SQRT_MKL_AVX512  MKL's AVX-512 float sqrt bit for bit, and the reset's means in torch.mean's own summation
- *                        order (8-lane cascade sum).  rsqrt14_table: VRSQRT14 over [1, 4) as 2^24 uint16 on the
- *                        current device (dgl_amd/data/rsqrt14_avx512.npz expands to it), owned by the caller and kept
- *                        alive while the model is set.  About 10 % slower state kernels.
+ *                        order (8-lane cascade sum).  rsqrt14_table: VRSQRT14 over [1, 4) as 2^16 uint16 on the
+ *                        current device, index = exponent parity << 15 | mantissa >> 8, value = (estimate's bits -
+ *                        0x3F000000) >> 7 (the estimate depends on no lower mantissa bit; exact powers of 4 are
+ *                        special-cased; dgl_amd/sqrt_model.py builds it from dgl_amd/data/rsqrt14_avx512.npz), owned by
+ *                        the caller and kept alive while the model is set.  Step kernels 2-3 us slower per launch.
  * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to. */
 #define DGL_SQRT_IEEE 0
 #define DGL_SQRT_MKL_AVX512 1

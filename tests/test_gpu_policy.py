@@ -47,7 +47,7 @@ def test_tsp_split_f16_agrees_with_f32(R, weights, device):
     assert (a[2] == b[2]).mean() >= 0.99
 
 
-@pytest.mark.parametrize("R,knn", [(600, 30), (512, 30), (64, 50)])     # the fused kernel (two shapes); rows of more than 32 tokens
+@pytest.mark.parametrize("R,knn", [(600, 30), (512, 30), (64, 50), (37, 100), (9, 127)])     # the 32-token kernel (two shapes); rows of 51 / 101 / 128 tokens (two and four tiles)
 def test_forward_gives_the_same_bits_on_every_call(R, knn, device):
     """Nothing in the forward pass depends on timing: no float atomics, and no instruction reads a register another
     one is still writing (a build that placed hand-written assembly next to matrix instructions with results in VGPRs
