@@ -250,3 +250,28 @@ def test_cvrp_wide_kernel_agrees_with_general_path(knn, kd, device):
     assert rel < 3e-5
     np.testing.assert_allclose(pa, pb, rtol=5e-4, atol=1e-7)
     assert (sa == sb).mean() >= 0.97
+
+
+def test_wide_kernel_range_guard_falls_back_to_the_general_path(device, monkeypatch):
+    """Rows of more than 32 tokens with activations beyond the binary16 range: the one-launch kernel reports them
+    (overflow_out) and the rollout is repeated through the general path, whose scaled splits take any magnitude - the
+    result is what the general path alone gives."""
+    from dgl_amd import _lib
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from oracle.dgl_oracle import random_weights
+    g = torch.Generator().manual_seed(6)
+    xy = torch.rand(6, 120, 2, generator=g).to(device)
+    start = torch.zeros(6, dtype=torch.int32, device=device)
+    w = random_weights("TSP", 5)
+    big = dict(w)
+    big["encoder.embedding.weight"] = w["encoder.embedding.weight"] * 3e5
+    eng = TspEngine(xy, 1, 50)
+    eng.greedy_rollout(PackedPolicy(w, _lib.PROBLEM_TSP, device), start)
+    assert eng.reran_f32 is False and int(eng.overflow.item()) == 0
+    eng.greedy_rollout(PackedPolicy(big, _lib.PROBLEM_TSP, device), start)
+    assert eng.reran_f32 is True
+    tour = eng.state["tour"].clone()
+    monkeypatch.setenv("DGL_WIDE_FORWARD", "0")
+    ref = TspEngine(xy, 1, 50)
+    ref.greedy_rollout(PackedPolicy(big, _lib.PROBLEM_TSP, device), start)
+    assert torch.equal(ref.state["tour"], tour)
