@@ -24,6 +24,8 @@ the workload's batch and at a batch large enough to fill the chip; ``measured_pe
 card delivers for a float4 triad / copy and for back-to-back matrix instructions on random
 operands; ``tsp10000_beam16`` and ``cvrp5000_train`` are BASELINE.json's configurations 4 and 5 on one GPU (a beam-16
 decode of TSP-10000 instances; a training decode step of the CVRP policy at knn = depot_knn = 100 on CVRP-5000 rows);
+``ieee_roots_mode`` the two headline workloads and the step kernel's saturating batch once more with correctly rounded
+square roots (the lines above run under the engines' default, the square-root model of the reference's torch build);
 ``cvrplib_k50_forward`` one policy evaluation on rows of 102 tokens (the CVRPLIB neighbourhoods, knn = depot_knn = 50).
 ``cpu_baseline`` is the oracle (the PyTorch-CPU restatement of the reference path) on a
 bounded sample.
@@ -234,6 +236,8 @@ def run_problem(problem, args, world, rank, dev, dist):
     bytes_knn = knn_bytes_per_row(N, 2 * knn if cvrp else knn, cvrp) * B
     ach_gbs = bytes_knn / (ms_knn * 1e-3) / 1e9 if ms_knn > 0 else 0.0
     kname = "policy_kernel_f16" if split else "policy_kernel_f32"
+    from dgl_amd import sqrt_model as _sqrt_model
+    sqrt_model_name = _sqrt_model.current(dev)
     out = {
         "metric": f"instances/sec, {problem.upper()}-{N} greedy decode (node selection)",
         "value": world * B * args.steps / elapsed,
@@ -244,7 +248,8 @@ def run_problem(problem, args, world, rank, dev, dist):
         "dtype": "f32 (f16 split-operand MFMA x3, f32 accumulate)" if split else "f32", "data": "synthetic",
         "config": {"workload": f"{problem.upper()}-{N} greedy decode, {B} uniform instances per GPU, "
                                f"k={knn}" + (f"/{knn}" if cvrp else "") + ", random-init weights",
-                   "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}"},
+                   "instances_per_gpu": B, "nodes": N, "knn": knn, "parallelism": f"instance-sharded x{world}",
+                   "sqrt_model": sqrt_model_name},
         "decode_steps_per_s": args.steps * decisions / elapsed,
         "row_decisions_per_s": world * B * args.steps * decisions / elapsed,
         "mean_tour_length": mean_len,
@@ -342,7 +347,7 @@ def main():
                                                               "decode_steps_per_s", "mean_tour_length", "roofline",
                                                               "roofline_knn", "cpu_baseline") if k in other}
         if not args.no_aux and world == 1:
-            out["reference_bits_mode"] = bench_reference_bits_mode(args, dev)
+            out["ieee_roots_mode"] = bench_ieee_roots_mode(args, dev)
             out["tsp10000_beam16"] = bench_tsp10000_beam(dev)
             out["cvrp5000_train"] = bench_cvrp5000_train(dev)
             out["cvrplib_k50_forward"] = bench_wide_forward(dev)
@@ -395,25 +400,29 @@ def knn_saturating(dev, problem: str, N: int, knn: int, rows: int = 16384):
             "tile_output_bytes": tile_by, "achieved_with_tile_output": (by + tile_by) / (ms * 1e-3) / 1e9}
 
 
-def bench_reference_bits_mode(args, dev):
-    """The headline workloads once more under the square-root model "mkl_avx512" (dgl_amd/sqrt_model.py): the state
-    kernels then reproduce the reference's own torch build bit for bit (MKL's AVX-512 sqrt, torch.mean's summation
-    order), which is the setting the >= 99 % identical-tours tests against the reference's tours run under; the lines
-    above use correctly rounded roots."""
+def bench_ieee_roots_mode(args, dev):
+    """The headline workloads once more with correctly rounded square roots (DGL_SQRT_MODEL=ieee, dgl_amd/sqrt_model.py).
+    The lines above run under the engines' default, the model of the reference's own torch build (MKL's AVX-512 sqrt,
+    torch.mean's summation order): the state is then the reference's bit for bit and the >= 99 % identical-tours tests
+    against the reference's tours hold; correctly rounded roots are the host-independent alternative, about 2 % faster
+    per rollout and 19 % at a saturating batch of the step kernel."""
     import copy
     from dgl_amd import sqrt_model
     a = copy.copy(args)
     a.no_aux, a.no_cpu_baseline, a.steps, a.warmup = True, True, min(args.steps, 2), 1
-    sqrt_model.use("mkl_avx512", dev)
+    sqrt_model.use("ieee", dev)
     try:
         res = {}
         for problem in (("tsp", "cvrp") if args.problem == "both" else (args.problem,)):
             r = run_problem(problem, a, 1, 0, dev, None)
+            sat = knn_saturating(dev, problem, r["config"]["nodes"], r["config"]["knn"])
             res[problem] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                            "policy_kernel_ms": r["roofline"]["avg_launch_ms"], "step_kernel_ms": r["roofline_knn"]["avg_launch_ms"]}
+                            "policy_kernel_ms": r["roofline"]["avg_launch_ms"], "step_kernel_ms": r["roofline_knn"]["avg_launch_ms"],
+                            "step_kernel_saturating_batch": {k: sat.get(k) for k in ("rows", "avg_launch_ms", "achieved", "frac")}}
     finally:
-        sqrt_model.use("ieee", dev)
-    res["note"] = "same workloads, square-root model mkl_avx512 (reference's torch build bit for bit); the headline uses IEEE roots"
+        sqrt_model.use(sqrt_model.default_model(), dev)
+    res["note"] = ("same workloads with correctly rounded square roots (DGL_SQRT_MODEL=ieee); the headline runs under the "
+                   "reference-bits model " + sqrt_model.default_model())
     return res
 
 

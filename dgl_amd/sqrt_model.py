@@ -1,9 +1,12 @@
 """Which square root the state kernels reproduce (include/dgl_amd.h: dgl_set_sqrt_model).
 
-    "ieee"        correctly rounded roots (default)
     "mkl_avx512"  what torch.sqrt / torch.cdist return on a CPU build of torch linked against MKL on an AVX-512 machine
                   - the setting the golden vectors of this repository were captured under - together with the reset's
                   means in torch.mean's own summation order: the device then carries the reference's state bit for bit.
+                  The engines' default (the library's own default, before any engine exists, is "ieee": this model needs
+                  a table from the host).
+    "ieee"        correctly rounded roots: the reference's algorithm independent of any host's math library; about 2 %
+                  faster rollouts, and what the C and PyTorch oracles of the tests restate.  DGL_SQRT_MODEL=ieee selects it.
 
 The setting is per device and process-wide; states reset after a change follow the new model."""
 from __future__ import annotations
@@ -16,6 +19,7 @@ import torch
 from . import _lib
 
 IEEE, MKL_AVX512 = 0, 1
+DEFAULT = "mkl_avx512"
 _TABLE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "rsqrt14_avx512.npz")
 _tables = {}          # device index -> the VRSQRT14 table on that device (kept alive while the library may read it)
 _current = {}         # device index -> model name
@@ -60,14 +64,18 @@ def use(model: str, device=None) -> None:
     _current[index] = model
 
 
+def default_model() -> str:
+    """The model the engines select: DGL_SQRT_MODEL from the environment, else the reference-bits model."""
+    return os.environ.get("DGL_SQRT_MODEL", "") or DEFAULT
+
+
 def apply_environment(device) -> None:
-    """DGL_SQRT_MODEL=mkl_avx512 in the environment selects that model on every device an engine is created on (once
-    per device; an explicit ``use`` afterwards still wins)."""
+    """Called when an engine is created: selects default_model() on the engine's device unless a model has been chosen
+    there already (once per device; an explicit ``use`` before or afterwards wins)."""
     index = torch.device(device).index
     index = torch.cuda.current_device() if index is None else index
-    name = os.environ.get("DGL_SQRT_MODEL", "")
-    if name and index not in _current:
-        use(name, torch.device("cuda", index))
+    if index not in _current:
+        use(default_model(), torch.device("cuda", index))
 
 
 def current(device=None) -> str:

@@ -71,7 +71,9 @@ DGL_API const char *dgl_last_error_string(void);
  *                        0x3F000000) >> 7 (the estimate depends on no lower mantissa bit; exact powers of 4 are
  *                        special-cased; dgl_amd/sqrt_model.py builds it from dgl_amd/data/rsqrt14_avx512.npz), owned by
  *                        the caller and kept alive while the model is set.  Step kernels 2-3 us slower per launch.
- * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to. */
+ * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to.
+ * The library starts with DGL_SQRT_IEEE (the other model needs the caller's table); the Python host (dgl_amd/sqrt_model.py)
+ * selects DGL_SQRT_MKL_AVX512 on every device it creates an engine on unless the environment says DGL_SQRT_MODEL=ieee. */
 #define DGL_SQRT_IEEE 0
 #define DGL_SQRT_MKL_AVX512 1
 DGL_API int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table);

@@ -66,6 +66,17 @@ def multirank_children():
     return _CHILDREN
 
 
+@pytest.fixture
+def ieee_roots(device):
+    """Correctly rounded square roots for the duration of a test (the engines default to the model of the reference's
+    torch build, dgl_amd/sqrt_model.py): for tests that compare bit for bit with the C / PyTorch oracles, which restate
+    the reference's algorithm with correctly rounded roots, and for the fused decode kernel, which is built for them."""
+    from dgl_amd import sqrt_model
+    sqrt_model.use("ieee", device)
+    yield sqrt_model
+    sqrt_model.use(sqrt_model.default_model(), device)
+
+
 def load_golden(name):
     """Returns (case dict of numpy arrays, weights dict of torch tensors)."""
     import torch

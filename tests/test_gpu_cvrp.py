@@ -148,7 +148,7 @@ def test_state_data_matches_golden(name, device):
 
 
 @pytest.mark.parametrize("N,knn,kd,until", [(150, 15, 20, None), (700, 15, 20, 60), (2500, 15, 15, 40)])
-def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
+def test_recurrences_bit_exact_vs_c_oracle(device, ieee_roots, N, knn, kd, until):
     """Synthetic instance, random feasible actions: state arithmetic and both neighbourhoods must be
     bit-identical to the plain-C oracle.  700 nodes: four waves share a row; 2500: they also share the
     compaction of the candidates."""
@@ -201,19 +201,22 @@ def test_recurrences_bit_exact_vs_c_oracle(device, N, knn, kd, until):
 @pytest.mark.parametrize("name,min_identical", [("cvrp_n100_b64_nn", 0.9), ("cvrp_n1000_b4_nn", 0.5),
                                                 ("cvrp_n100_b256_nn_tours", 0.99),
                                                 ("cvrp_n1000_b128_nn_tours", 0.99),
-                                                ("cvrp_n1000_b512_nn_tours", 0.97),
-                                                ("cvrp_n1000_b128_clustered_nn_tours", 0.8),
+                                                ("cvrp_n1000_b512_nn_tours", 0.99),
+                                                ("cvrp_n1000_b128_clustered_nn_tours", 0.95),
                                                 ("cvrp_n20_b64_nn", 0.98), ("cvrp_n24_b64_nn_tours", 0.98),
                                                 ("cvrp_n25_b64_nn_tours", 0.98)])
 def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
-    """Greedy routes against the reference's own, trained checkpoint.  The 512-instance population of the headline
-    size is held to 97 % against the reference's run and to 99 % against the second opinion its fixture carries
-    (oracle/make_ieee_tours.py: the reference's algorithm with correctly rounded square roots and a stable argsort):
-    the reference's own run shares only 503 of 512 routes with that second run - its torch build's float sqrt is one
-    ulp low on 0.6 % of inputs, the running standard deviations amplify last bits by N / #unvisited and the min-max
-    normalisation by another hundredfold, and 32 of the 512 trajectories pass an exact distance tie at the edge of a
-    neighbourhood, which its unstable argsort resolves its own way - so 98 % is what an implementation with IEEE
-    square roots can share with it (tools/dbg_mismatch*.py locate every differing decision)."""
+    """Greedy routes against the reference's own, trained checkpoint, under the engines' default square-root model
+    (the reference's torch build, dgl_amd/sqrt_model.py): >= 99 % on every uniform population, the 512 instances of the
+    headline size included (507/512; what is left are exact distance ties at the edge of a neighbourhood, which the
+    reference's unstable argsort resolves its own way - 32 of the 512 trajectories pass one - and decisions whose two
+    best logits differ by less than the policy arithmetic's 1e-5).
+    The fixtures that carry a second opinion (oracle/make_ieee_tours.py: the reference's algorithm with correctly
+    rounded square roots and a stable argsort) are then decoded once more with correctly rounded roots: that run must
+    be reproduced on >= 99 %, while the reference's own run shares only 503 of 512 routes with it - its torch build's
+    float sqrt is one ulp low on 0.6 % of inputs, the running standard deviations amplify last bits by N / #unvisited
+    and the min-max normalisation by another hundredfold - so about 98 % is what correctly rounded roots can share
+    with the reference's run (tools/dbg_mismatch*.py locate every differing decision)."""
     from dgl_amd._lib import PROBLEM_CVRP
     from dgl_amd.engine import PackedPolicy
     case, weights = load_golden(name)
@@ -233,7 +236,14 @@ def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device)
     assert rel < 1e-4
     np.testing.assert_allclose(length[same], case["length"][same], rtol=3e-6)
     if "ieee/nodes" in case:
+        from dgl_amd import sqrt_model
         from test_gpu_tsp import _second_opinion
+        sqrt_model.use("ieee", device)
+        try:
+            eng.greedy_rollout(pol, start)
+        finally:
+            sqrt_model.use(sqrt_model.default_model(), device)
+        nodes, flags = eng.state["nodes"].cpu().numpy(), eng.state["flags"].cpu().numpy()
         got = nodes.astype(np.int32) + (eng.N + 1) * flags.astype(np.int32)
         ieee = case["ieee/nodes"].astype(np.int32) + (eng.N + 1) * case["ieee/flags"].astype(np.int32)
         ref = case["nodes"].astype(np.int32) + (eng.N + 1) * case["flags"].astype(np.int32)
@@ -241,7 +251,7 @@ def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device)
 
 
 @pytest.mark.parametrize("name", ["cvrp_n1000_b128_nn_tours", "cvrp_n1000_b128_clustered_nn_tours"])
-def test_route_mismatches_attributed_to_reset_moments(name, device):
+def test_route_mismatches_attributed_to_reset_moments(name, device, ieee_roots):
     """The CVRP counterpart of test_tour_mismatches_attributed_to_reset_moments (tests/test_gpu_tsp.py): the population
     decoded from the device's own reset and from the reference's captured reset moments; identical routes for both."""
     from dgl_amd._lib import PROBLEM_CVRP

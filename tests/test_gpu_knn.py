@@ -8,6 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _correctly_rounded_roots(ieee_roots):
+    """The plain-C oracle takes correctly rounded square roots: so does the device in this file."""
+    yield
+
+
 def _run_case(device, xy, visit_order, knn, check_until=None, rows=None):
     """xy [B,N,2] float32 numpy; visit_order [B,N] permutation; drives the kernel with that order and
     checks idx/avg/sd against the C oracle after every step (rows: only these rows are compared)."""

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("N", [20, 24, 25])
-def test_cvrp_training_state_over_three_coordinates(N, device):
+def test_cvrp_training_state_over_three_coordinates(N, device, ieee_roots):
     """CVRP/CVRPEnv.py:519: the training reset measures distances over (x, y, demand).  N = 24 is the last size on the
     pair-by-pair evaluation (25 points with the depot), N = 25 the first on the matrix product.  From the oracle's reset
     moments (the device sums them in another order) every step's running statistics, capacities and both

@@ -17,7 +17,7 @@ def mkl(device):
     from dgl_amd import sqrt_model
     sqrt_model.use("mkl_avx512", device)
     yield sqrt_model
-    sqrt_model.use("ieee", device)
+    sqrt_model.use(sqrt_model.default_model(), device)
 
 
 def test_square_roots_bit_for_bit(device, mkl):

@@ -125,17 +125,18 @@ def test_greedy_rollout_length(name, device):
                                                 ("tsp_n100_b512_nn_tours", 0.99),
                                                 ("tsp_n1000_b128_nn_tours", 0.99),
                                                 ("tsp_n1000_b512_nn_tours", 0.99),
-                                                ("tsp_n1000_b128_clustered_nn_tours", 0.9),
+                                                ("tsp_n1000_b128_clustered_nn_tours", 0.97),
                                                 ("tsp_n20_b64_nn", 0.98), ("tsp_n25_b64_nn_tours", 0.98)])
 def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     """With the trained checkpoint fixture (peaked action distributions) the greedy tours must be
-    the reference's own: >= 99 % of instances on the populations (512 instances of 100 nodes, 128 instances of
-    the headline size, 1000 nodes), mean length within 0.01 %.  (The small cases only bound the damage one flipped arg-max can do to the ratio.)
-    Clustered instances (seven Gaussian clusters of sigma 0.04: the kind of set the reference evaluates beside the
-    uniform one, TSP/test.py:131) are a different matter: the reference's own tours are not reproducible there - moving
-    the reset's mean / std by one ulp, which is what another summation order of torch.mean does, changes a quarter of
-    them (oracle/rounding_sensitivity.py; none of the uniform ones) - so only the mean length is held to 0.01 % and the
-    identical fraction is reported against a loose floor."""
+    the reference's own: >= 99 % of instances on the populations (512 instances of 100 nodes, 128 and 512 instances of
+    the headline size, 1000 nodes), mean length within 0.01 %, under the engines' default square-root model (the
+    reference's torch build: dgl_amd/sqrt_model.py).  (The small cases only bound the damage one flipped arg-max can do
+    to the ratio.)  Clustered instances (seven Gaussian clusters of sigma 0.04: the kind of set the reference evaluates
+    beside the uniform one, TSP/test.py:131) hang on the last bit far more often - moving the reset's mean / std by
+    one ulp changes a quarter of the reference's own tours there (oracle/rounding_sensitivity.py; none of the uniform
+    ones) - and are held to 97 %.
+    Fixtures that carry a second opinion are then decoded once more with correctly rounded roots (_second_opinion)."""
     from dgl_amd.engine import PackedPolicy
     from dgl_amd._lib import PROBLEM_TSP
     case, weights = load_golden(name)
@@ -153,7 +154,13 @@ def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     assert rel < 1e-4
     np.testing.assert_allclose(length[same], case["length"][same], rtol=2e-6)
     if "ieee/tour" in case:
-        _second_opinion(name, tour, case["ieee/tour"], case["tour"], case["ref_tie"])
+        from dgl_amd import sqrt_model
+        sqrt_model.use("ieee", device)
+        try:
+            eng.greedy_rollout(pol, start)
+        finally:
+            sqrt_model.use(sqrt_model.default_model(), device)
+        _second_opinion(name, eng.state["tour"].cpu().numpy(), case["ieee/tour"], case["tour"], case["ref_tie"])
 
 
 def _second_opinion(name, got, ieee, ref, tie):
@@ -166,14 +173,15 @@ def _second_opinion(name, got, ieee, ref, tie):
     same_ieee = (got == ieee).all(axis=1)
     same_ref = (got == ref).all(axis=1)
     ref_vs_ieee = (ref == ieee).all(axis=1)
-    print(f"{name}: identical to the correctly-rounded-sqrt run of the reference's algorithm {int(same_ieee.sum())}/{len(same_ieee)}"
+    print(f"{name}, correctly rounded roots (DGL_SQRT_MODEL=ieee): identical to the reference's own run "
+          f"{int(same_ref.sum())}/{len(same_ref)}; identical to the correctly-rounded-sqrt run of the reference's algorithm {int(same_ieee.sum())}/{len(same_ieee)}"
           f" ({100 * same_ieee.mean():.2f} %); the reference's own run shares {int(ref_vs_ieee.sum())}/{len(tie)} with that run; "
           f"{int(tie.sum())} instances pass a neighbourhood tie on the reference's trajectory, without them the device "
           f"shares {int((same_ref & ~tie).sum())}/{int((~tie).sum())} with the reference")
     assert same_ieee.mean() >= 0.99
 
 
-def test_fused_greedy_decode_is_bit_identical(device, monkeypatch):
+def test_fused_greedy_decode_is_bit_identical(device, monkeypatch, ieee_roots):
     """dgl_tsp_greedy_decode (the whole decode loop in one launch) against two launches per decision: the same device
     code runs in both, so tours and lengths must be equal bit for bit; odd row count, neighbourhoods that shrink at
     the end of the tour."""
@@ -194,7 +202,7 @@ def test_fused_greedy_decode_is_bit_identical(device, monkeypatch):
     assert np.array_equal(ref_tour.cpu().numpy(), case["tour"][:33])
 
 
-def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch):
+def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch, ieee_roots):
     """An odd row count leaves the last workgroup of the fused decode with a spare pair of waves, which walks the last
     row without storing anything.  Rows of 2100 nodes keep several groups of loads in flight per wave (and take the
     shared-compaction path), so a second in-place update of the last row's moments would show as different tours."""
@@ -220,8 +228,9 @@ def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["tsp_n1000_b128_nn_tours", "tsp_n1000_b128_clustered_nn_tours"])
-def test_tour_mismatches_attributed_to_reset_moments(name, device):
-    """Where do the tours that differ from the reference's come from?  The device's reset sums its distances in
+def test_tour_mismatches_attributed_to_reset_moments(name, device, ieee_roots):
+    """(With correctly rounded roots; under the default model the reset already carries the reference's moments bit
+    for bit.)  Where do the tours that differ from the reference's come from?  The device's reset sums its distances in
     binary64 and rounds once; torch.mean / torch.std round along a float cascade, so the two sets of starting moments
     differ in the last bit here and there, and the recurrences and the min-max normalisation carry that into the
     logits.  This decodes the population twice - from the device's own reset, and with the reference's captured reset
