@@ -143,3 +143,20 @@ def test_cvrp_state_bit_for_bit_along_the_reference_route(name, device, mkl):
             tiles += 1
     print(f"{name}: {checked} state snapshots and {tiles} token tiles equal to the reference's bit for bit")
     assert checked >= 2
+
+
+def test_square_roots_follow_the_recorded_instruction_on_random_inputs(device, mkl):
+    """dgl_sqrt_apply against the NumPy restatement of MKL's AVX-512 float sqrt over the recorded VRSQRT14 table
+    (tools/make_rsqrt14_table.py::model_sqrt, itself equal to torch.sqrt on the fixture above): four million inputs
+    over sixty binades, the exact powers of two and four among them."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from make_rsqrt14_table import model_sqrt
+    from dgl_amd.sqrt_model import rsqrt14_table_full
+    rng = np.random.default_rng(5)
+    x = (rng.random(4_000_000, dtype=np.float32) + np.float32(1.0)) * np.exp2(rng.integers(-30, 30, 4_000_000)).astype(np.float32)
+    x[:64] = np.exp2(np.arange(-32, 32)).astype(np.float32)
+    want = model_sqrt(x, rsqrt14_table_full())
+    got = mkl.apply(torch.from_numpy(x).to(device)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (want != np.sqrt(x)).mean() > 0.003
