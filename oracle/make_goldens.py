@@ -364,6 +364,10 @@ TRAINED_CASES = {
     # more than 32 tokens per row: the CVRPLIB setting (CVRP/test_cvrplib.py:326-327) and a TSP row of 51 tokens
     "cvrp_n200_b4_k50_nn": ("cvrp", dict(seed=321, B=4, N=200, knn=50, depot_knn=50)),
     "tsp_n200_b4_k50_nn": ("tsp", dict(seed=321, B=4, N=200, knn=50)),
+    # populations at the headline size with the CVRPLIB neighbourhoods (CVRP/test_cvrplib.py:326-327: knn = depot_knn = 50):
+    # rows of 51 / 102 tokens, the sizes the one-launch kernel for 33..128 tokens serves
+    "tsp_n1000_b64_k50_nn_tours": ("tsp", dict(seed=5050, B=64, N=1000, knn=50, light="tours16")),
+    "cvrp_n1000_b64_k50_nn_tours": ("cvrp", dict(seed=5050, B=64, N=1000, knn=50, depot_knn=50, light="tours16")),
     # at most 25 points per instance: torch.cdist evaluates the distances pair by pair instead of through a matrix
     # product (20 customers + depot = 21 points; 24 + 1 = 25 is the last size on that path, 25 + 1 the first beyond it)
     "tsp_n20_b64_nn": ("tsp", dict(seed=2020, B=64, N=20, knn=30)),
