@@ -127,7 +127,8 @@ def test_greedy_rollout_length(name, device):
                                                 ("tsp_n1000_b512_nn_tours", 0.99),
                                                 ("tsp_n1000_b128_clustered_nn_tours", 0.97),
                                                 ("tsp_n20_b64_nn", 0.98), ("tsp_n25_b64_nn_tours", 0.98),
-                                                ("tsp_n1000_b64_k50_nn_tours", 0.98)])     # 51 tokens per row: the one-launch kernel for 33..128
+                                                ("tsp_n1000_b64_k50_nn_tours", 0.98),      # 51 tokens per row: the one-launch kernel for 33..128
+                                                ("tsp_n10000_b2_nn_tours", 1.0)])          # configuration 4's size: 9 999 decisions per tour
 def test_greedy_tours_identical_trained_checkpoint(name, min_identical, device):
     """With the trained checkpoint fixture (peaked action distributions) the greedy tours must be
     the reference's own: >= 99 % of instances on the populations (512 instances of 100 nodes, 128 and 512 instances of
