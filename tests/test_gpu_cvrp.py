@@ -205,7 +205,8 @@ def test_recurrences_bit_exact_vs_c_oracle(device, ieee_roots, N, knn, kd, until
                                                 ("cvrp_n1000_b128_clustered_nn_tours", 0.95),
                                                 ("cvrp_n20_b64_nn", 0.98), ("cvrp_n24_b64_nn_tours", 0.98),
                                                 ("cvrp_n25_b64_nn_tours", 0.98),
-                                                ("cvrp_n1000_b64_k50_nn_tours", 0.98)])    # 102 tokens per row (CVRPLIB neighbourhoods)
+                                                ("cvrp_n1000_b64_k50_nn_tours", 0.98),
+                                                ("cvrp_n5000_b2_k100_nn_tours", 1.0)])     # configuration 5's size: 202 tokens per row    # 102 tokens per row (CVRPLIB neighbourhoods)
 def test_greedy_routes_identical_trained_checkpoint(name, min_identical, device):
     """Greedy routes against the reference's own, trained checkpoint, under the engines' default square-root model
     (the reference's torch build, dgl_amd/sqrt_model.py): >= 99 % on every uniform population, the 512 instances of the
