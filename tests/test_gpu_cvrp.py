@@ -152,11 +152,15 @@ def test_recurrences_bit_exact_vs_c_oracle(device, ieee_roots, N, knn, kd, until
     """Synthetic instance, random feasible actions: state arithmetic and both neighbourhoods must be
     bit-identical to the plain-C oracle.  700 nodes: four waves share a row; 2500: they also share the
     compaction of the candidates."""
+    _recurrences_vs_c_oracle(device, N, knn, kd, until)
+
+
+def _recurrences_vs_c_oracle(device, N, knn, kd, until, seed=3, B=2):
+    """(correctly rounded roots must be selected by the caller: the plain-C oracle takes them)"""
     from dgl_amd.engine import CvrpEngine
     from oracle import cref
     lib = cref.load()
-    rng = np.random.default_rng(3)
-    B = 2
+    rng = np.random.default_rng(seed)
     M = N + 1
     xy = rng.random((B, M, 2), dtype=np.float32)
     dem = np.concatenate([np.zeros((B, 1), np.float32), (rng.integers(1, 200, (B, N)) / 500.0).astype(np.float32)], 1)

@@ -219,7 +219,8 @@ def test_tsp_wide_kernel_agrees_with_general_path(knn, weights, device):
     rel = float((np.abs(la - lb) / scale).max())
     print(f"knn={knn} {weights}: max relative logit difference wide kernel vs general path {rel:.2e}")
     assert rel < 3e-5
-    np.testing.assert_allclose(pa, pb, rtol=5e-4, atol=1e-7)
+    # a probability moves by (its value) x (twice the largest logit difference): logits reach several hundred here
+    np.testing.assert_allclose(pa, pb, rtol=5e-4 + 2 * float(np.abs(la - lb).max()), atol=1e-7)
     assert (sa == sb).mean() >= 0.97 and eng.overflow.item() == 0
 
 
@@ -248,7 +249,8 @@ def test_cvrp_wide_kernel_agrees_with_general_path(knn, kd, device):
     rel = float((np.abs(la - lb) / scale).max())
     print(f"knn={knn}/{kd}: max relative logit difference wide kernel vs general path {rel:.2e}")
     assert rel < 3e-5
-    np.testing.assert_allclose(pa, pb, rtol=5e-4, atol=1e-7)
+    # a probability moves by (its value) x (twice the largest logit difference): logits reach several hundred here
+    np.testing.assert_allclose(pa, pb, rtol=5e-4 + 2 * float(np.abs(la - lb).max()), atol=1e-7)
     assert (sa == sb).mean() >= 0.97
 
 
