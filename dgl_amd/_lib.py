@@ -99,7 +99,7 @@ SIGNATURES = {
                                    c_void_p]),
     "dgl_beam_advance_compact": (c_int32, [POINTER(PolicyIO), c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                            c_int32, c_void_p, c_void_p, c_void_p]),
-    "dgl_set_sqrt_model": (c_int32, [c_int32, c_void_p]),
+    "dgl_set_sqrt_model": (c_int32, [c_int32]),
     "dgl_sqrt_apply": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 

@@ -44,29 +44,28 @@ void dgl_max_dynamic_lds(const void *kernel, int bytes) {
 }
 
 // ---- square-root model (common.h: DglSqrtIeee / DglSqrtMkl) -----------------------------------------------------
-// One setting per device, read by the launchers of the state kernels; NULL = correctly rounded roots.
+// One setting per device, read by the launchers of the state kernels; stored as model + 1, 0 = never set = the default
+// DGL_SQRT_MKL_AVX512.
 #define DGL_MAX_DEVICES 64
-static const uint16_t *g_sqrt_table[DGL_MAX_DEVICES];
+static int g_sqrt_model[DGL_MAX_DEVICES];
 static std::mutex g_sqrt_mutex;
 
-const uint16_t *dgl_sqrt_table() {
+bool dgl_sqrt_reference_bits() {
     int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= DGL_MAX_DEVICES) return nullptr;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= DGL_MAX_DEVICES) return true;
     std::lock_guard<std::mutex> lock(g_sqrt_mutex);
-    return g_sqrt_table[device];
+    return g_sqrt_model[device] == 0 || g_sqrt_model[device] == DGL_SQRT_MKL_AVX512 + 1;
 }
 
-extern "C" int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table) {
+extern "C" int dgl_set_sqrt_model(int32_t model) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return dgl_set_error(DGL_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
     if (device < 0 || device >= DGL_MAX_DEVICES) return dgl_set_error(DGL_ERR_UNSUPPORTED, "device ordinal %d", device);
     if (model != DGL_SQRT_IEEE && model != DGL_SQRT_MKL_AVX512)
         return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "unknown square-root model %d", model);
-    if (model == DGL_SQRT_MKL_AVX512 && rsqrt14_table == nullptr)
-        return dgl_set_error(DGL_ERR_INVALID_ARGUMENT, "DGL_SQRT_MKL_AVX512 needs the VRSQRT14 table (2^16 uint16 on this device)");
     std::lock_guard<std::mutex> lock(g_sqrt_mutex);
-    g_sqrt_table[device] = model == DGL_SQRT_MKL_AVX512 ? rsqrt14_table : nullptr;
+    g_sqrt_model[device] = model + 1;
     return DGL_OK;
 }
 

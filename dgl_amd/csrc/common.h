@@ -11,7 +11,7 @@
 
 // host-side error plumbing (api.cpp)
 int dgl_set_error(int code, const char *fmt, ...);
-const uint16_t *dgl_sqrt_table();                             // the current device's VRSQRT14 table, NULL: IEEE roots (api.cpp)
+bool dgl_sqrt_reference_bits();                               // the current device's square-root model is DGL_SQRT_MKL_AVX512 (api.cpp)
 void dgl_max_dynamic_lds(const void *kernel, int bytes);      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
 #define DGL_CHECK_ARG(cond, ...)                                           \
     do {                                                                   \
@@ -104,87 +104,107 @@ template <bool DIRECT_>
 struct DglSqrtIeeeT {
     static constexpr unsigned ULPS = 4u;
     static constexpr bool DIRECT = DIRECT_;
-    static constexpr bool BATCHED = false;      // roots are taken one at a time where they are needed
+    static constexpr bool WAVE_WIDE = false;    // no root needs the other lanes of its wave
+    struct Lanes {};
+    __device__ __forceinline__ Lanes lanes() const { return Lanes{}; }
+    __device__ __forceinline__ float all(const Lanes &, float x) const { return dgl_sqrt(x); }
+    __device__ __forceinline__ float dist_all(const Lanes &, float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float operator()(float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float pk(float x) const { return dgl_sqrt_pk(x); }
     __device__ __forceinline__ float dist(float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float dist_pk(float x) const { return dgl_sqrt_pk(x); }
 };
 typedef DglSqrtIeeeT<false> DglSqrtIeee;
+// VRSQRT14 in closed form.  Over [1, 4) the instruction's estimate is piecewise linear in the input's mantissa: 64
+// segments (lowest bit of the biased exponent, upper 5 mantissa bits), and inside a segment
+//   (estimate's bits - 0x3F000000) >> 7  =  (C - S m) >> 9,     m = mantissa bits 17..8,
+// with one integer pair (C, S) per segment.  The pairs below were solved from the instruction's recorded values
+// (tools/make_rsqrt14_table.py: for every segment exactly one pair reproduces its 1024 values; the estimate depends on no
+// lower mantissa bit and scales exactly with powers of 4; tests/test_host_cpu.py re-checks all 2^16 recorded values
+// against these constants).  {C, -S}, index = (bits >> 18) & 63.
+static __constant__ int2 DGL_RSQRT14_SEG[64] = {
+    {13896320, -707}, {13171840, -675}, {12480000, -647}, {11817472, -619},
+    {11183616, -595}, {10574720, -571}, {9990272, -549}, {9428096, -527},
+    {8887936, -509}, {8367488, -491}, {7864960, -473}, {7380608, -457},
+    {6912640, -441}, {6460672, -427}, {6023296, -413}, {5600640, -401},
+    {5190528, -389}, {4792704, -377}, {4407168, -365}, {4033664, -355},
+    {3670400, -345}, {3317504, -335}, {2974208, -325}, {2640896, -317},
+    {2316544, -309}, {2000512, -301}, {1692544, -293}, {1392384, -285},
+    {1100416, -279}, {814720, -271}, {536576, -265}, {264960, -259},
+    {33551488, -1001}, {32526464, -955}, {31548032, -915}, {30611712, -877},
+    {29714176, -841}, {28853120, -807}, {28026496, -775}, {27232384, -747},
+    {26467584, -719}, {25731200, -693}, {25021312, -669}, {24336896, -647},
+    {23675136, -625}, {23035136, -603}, {22417280, -585}, {21818752, -567},
+    {21238656, -549}, {20676992, -533}, {20131712, -517}, {19602432, -501},
+    {19089024, -487}, {18590080, -473}, {18105344, -461}, {17633664, -449},
+    {17174400, -437}, {16727424, -425}, {16292608, -415}, {15867648, -403},
+    {15454080, -393}, {15051520, -385}, {14657408, -375}, {14273792, -367},
+};
 template <bool DIRECT_>
 struct DglSqrtMklT {
     static constexpr unsigned ULPS = 8u;
     static constexpr bool DIRECT = DIRECT_;
-    // The scan loops take the roots of a whole group of node chunks together (roots<K>): the table look-ups of the K
-    // roots are then K loads in flight behind ONE wave-uniform branch instead of K dependent round trips (nearly
-    // every wave has some lane that needs the table: one input in ten passes the filter).
-    static constexpr bool BATCHED = true;
-    const uint16_t *tab;
-    // the filter: the exact root lies more than DGL_MKL_FILTER / 2 ulp below the correctly rounded one.  Over all 2^24
-    // inputs of [1, 4) (the arithmetic scales exactly with powers of 4) MKL's result is the float below the correctly
-    // rounded root on 98 955 of them, the closest one 0.43991 ulp below it (its deficit is about 3/8 of the squared
-    // relative error of the 14-bit estimate); 0.4375 leaves a margin four orders above the filter's own rounding.
-    // Fewer flagged lanes = fewer cache lines per table load: 6 % of the lanes instead of 10 % at 0.4 ulp is worth
-    // 2.5 % of the step kernel's time at a saturating batch.
-#ifndef DGL_MKL_FILTER
-#define DGL_MKL_FILTER 0.875f
-#endif
-    __device__ __forceinline__ static bool needs_table(float x, float s0) {
-        const float ulp = __fsub_rn(s0, __uint_as_float(__float_as_uint(s0) - 1u));
-        return __fmaf_rn(-s0, s0, x) < -DGL_MKL_FILTER * __fmul_rn(s0, ulp);
+    // Where all 64 lanes of a wave are active (the scan loops, the candidates' feature rows) a root is taken with
+    // all(ln, x) / dist_all(ln, x): every lane goes through the closed form, the segment constants fetched from the
+    // lanes' registers (Lanes: lane l holds segment l) by ds_bpermute - no memory access, no filter.  ds_bpermute
+    // returns 0 for a lane that is switched off, hence the condition; kernels of this model (WAVE_WIDE) therefore take
+    // those roots before their per-lane guards.  Every other place uses operator() / dist(), which look the constants
+    // up in memory and work under any lane mask.
+    static constexpr bool WAVE_WIDE = true;
+    struct Lanes {
+        int c, ns;
+    };
+    __device__ __forceinline__ Lanes lanes() const {
+        const int2 e = DGL_RSQRT14_SEG[threadIdx.x & 63];
+        return Lanes{e.x, e.y};
     }
-    __device__ __forceinline__ static unsigned table_index(float x) {
+    // MKL's refinement of the estimate whose segment constants are (c, ns): s = x y, result = fma(fma(-s, s, x), y / 2, s)
+    // (x = +0 gives +0: the estimate's exponent stays finite)
+    __device__ __forceinline__ static float refine(float x, int c, int ns) {
         const unsigned b = __float_as_uint(x);
-        const int e = (int)(b >> 23) - 127, p = e & 1;
-        return ((unsigned)p << 23) | (b & 0x7FFFFFu);
-    }
-    __device__ __forceinline__ static float refined(float x, unsigned i, unsigned t) {
-        const int e = (int)(__float_as_uint(x) >> 23) - 127, p = e & 1, q = (e - p) >> 1;
-        unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + (t << 7);
-        yb -= (unsigned)q << 23;
+        const unsigned frac = ((unsigned)(c + __mul24(ns, (int)((b >> 8) & 1023u))) >> 9) << 7;
+        // exponent: y = 2^-q (0.5 + frac), q = floor((biased exponent - 127) / 2)
+        const unsigned yb = 0x5F000000u - (((b + 0x00800000u) >> 1) & 0x7F800000u) + frac;
         const float y = __uint_as_float(yb);
         const float s = __fmul_rn(x, y), h = __fmul_rn(0.5f, y);
         return __fmaf_rn(__fmaf_rn(-s, s, x), h, s);
     }
-    // out[k] = the model's root of x[k], k < K (distance roots under DIRECT: the correctly rounded ones)
-    template <int K>
-    __device__ __forceinline__ void roots(const float (&x)[K], float (&out)[K], bool distance) const {
-        bool need[K];
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            out[k] = dgl_sqrt(x[k]);
-            need[k] = !(DIRECT && distance) && needs_table(x[k], out[k]);
-            any = any || need[k];
+    // +0 and positive normal numbers go through the closed form; everything else (negative, NaN, +inf, denormal, -0)
+    // takes the hardware's root as under the other model
+    __device__ __forceinline__ static bool ordinary(float x) { return __builtin_amdgcn_classf(x, 0x140); }
+    // the model's root of x; all 64 lanes active
+    __device__ __forceinline__ float all(const Lanes &ln, float x) const {
+#ifdef DGL_MKL_FAKE
+        return dgl_sqrt(x);
+#endif
+        const int addr = (int)((__float_as_uint(x) >> 16) & 0xFCu);
+        const int c = __builtin_amdgcn_ds_bpermute(addr, ln.c), ns = __builtin_amdgcn_ds_bpermute(addr, ln.ns);
+        float out = refine(x, c, ns);
+        const bool odd = !ordinary(x);
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+            if (odd) out = dgl_sqrt(x);
         }
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-            unsigned idx[K], t[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                idx[k] = need[k] ? table_index(x[k]) : 0u;      // (the others read entry 0: one shared line)
-                t[k] = tab[idx[k] >> 8];
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (need[k]) out[k] = refined(x[k], idx[k], t[k]);
-        }
+        return out;
     }
+    // (distance roots under DIRECT: the correctly rounded ones)
+    __device__ __forceinline__ float dist_all(const Lanes &ln, float x) const { return DIRECT ? dgl_sqrt(x) : all(ln, x); }
     __device__ __forceinline__ float dist(float x) const { return DIRECT ? dgl_sqrt(x) : (*this)(x); }
     __device__ __forceinline__ float dist_pk(float x) const { return dist(x); }
+    // one root under any lane mask: the correctly rounded root, replaced where MKL's result can differ from it.  Over all
+    // 2^24 inputs of [1, 4) MKL's result is the float below the correctly rounded root on 98 955 of them, the closest
+    // one 0.43991 ulp below it (its deficit is about 3/8 of the squared relative error of the 14-bit estimate): only
+    // roots that were rounded up by more than DGL_MKL_FILTER / 2 = 0.4375 ulp are evaluated again.
+#ifndef DGL_MKL_FILTER
+#define DGL_MKL_FILTER 0.875f
+#endif
     __device__ __forceinline__ float operator()(float x) const {
         const float s0 = dgl_sqrt(x);
         const float ulp = __fsub_rn(s0, __uint_as_float(__float_as_uint(s0) - 1u));
         const float r = __fmaf_rn(-s0, s0, x);                  // x - s0^2: root - s0 ~ r / (2 s0)
         float res = s0;
-        if (r < -DGL_MKL_FILTER * __fmul_rn(s0, ulp)) {                   // (see needs_table)
-            const unsigned b = __float_as_uint(x);
-            const int e = (int)(b >> 23) - 127, p = e & 1, q = (e - p) >> 1;
-            const unsigned i = ((unsigned)p << 23) | (b & 0x7FFFFFu);
-            unsigned yb = i == 0u ? 0x3F800000u : 0x3F000000u + ((unsigned)tab[i >> 8] << 7);
-            yb -= (unsigned)q << 23;
-            const float y = __uint_as_float(yb);
-            const float s = __fmul_rn(x, y), h = __fmul_rn(0.5f, y);
-            res = __fmaf_rn(__fmaf_rn(-s, s, x), h, s);
+        if (r < -DGL_MKL_FILTER * __fmul_rn(s0, ulp) && ordinary(x)) {
+            const int2 e = DGL_RSQRT14_SEG[(__float_as_uint(x) >> 18) & 63u];
+            res = refine(x, e.x, e.y);
         }
         return res;
     }

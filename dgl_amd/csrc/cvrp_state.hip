@@ -64,15 +64,18 @@ __device__ __forceinline__ float cvrp_cross_depot(float x, float y, float z, flo
 
 // raw data row of a node at p with demand dem and running statistics (a, sd)
 // (CVRP/CVRPEnv.py:696,718,746,782,801); returns d(j, depot)
-template <bool D3, class SQ>
-__device__ __forceinline__ float cvrp_row(const SQ &sq, const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f) {
+// ALL: called by all 64 lanes of the wave together (the model's wave-wide roots, common.h)
+template <bool D3, bool ALL = false, class SQ>
+__device__ __forceinline__ float cvrp_row(const SQ &sq, const CvrpRowCtx &cx, float2 p, float dem, float a, float sd, float *f,
+                                          const typename SQ::Lanes &ln = typename SQ::Lanes{}) {
     const float nj = cvrp_norm<D3, SQ::DIRECT>(p.x, p.y, dem);
-    const float d0 = sq.dist(dgl_chain_sq(cvrp_cross_depot<D3, SQ::DIRECT>(p.x, p.y, dem, cx.x0, cx.y0), nj, cx.n0));   // d(j, depot)
+    auto root = [&](float r2) { return ALL ? sq.dist_all(ln, r2) : sq.dist(r2); };
+    const float d0 = root(dgl_chain_sq(cvrp_cross_depot<D3, SQ::DIRECT>(p.x, p.y, dem, cx.x0, cx.y0), nj, cx.n0));   // d(j, depot)
     const float den = __fadd_rn(d0, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
     f[2] = dem;
-    f[3] = sq.dist(dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
+    f[3] = root(dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(p.x, p.y, dem, cx.xc, cx.yc, cx.zc), nj, cx.nc));   // d(j, current)
     f[4] = a;
     f[5] = sd;
     f[6] = __fdiv_rn(__fsub_rn(cx.y0, p.y), den);
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
     };
     Group nxt;
     request(j_begin, nxt);
+    const typename SQ::Lanes sq_lanes = sq.lanes();         // (all 64 lanes are active here and at the top of the scan loop)
     // visited words of 64 consecutive chunks, one per lane; the word of a chunk is read back as a
     // wave-uniform lane mask (bit = lane) with the excluded nodes of that chunk added
     unsigned long long vis_words = 0;
@@ -185,36 +189,27 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
-        // models that take their roots in batches (common.h, BATCHED): both roots of all chunks of the group first
-        float a1b[STEP_UNROLL], s1b[STEP_UNROLL];
-        if constexpr (SQ::BATCHED && UPDATE) {
-            float rad[STEP_UNROLL], dcolb[STEP_UNROLL], item[STEP_UNROLL];
-#pragma unroll
-            for (int q = 0; q < STEP_UNROLL; ++q) {
-                const float x = g.p[q].x, y = g.p[q].y;
-                rad[q] = dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]),
-                                      cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]), cx.nc);
-            }
-            sq.roots(rad, dcolb, true);
-#pragma unroll
-            for (int q = 0; q < STEP_UNROLL; ++q) {
-                const float a0 = g.a0[q], s0 = g.s0[q], dcol = dcolb[q];
-                a1b[q] = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);                          // :711
-                const float e = __fsub_rn(dcol, a0);
-                float it = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
-                item[q] = it < 0.0f ? 0.0f : it;                                                     // :735-736
-            }
-            sq.roots(item, s1b, false);
-        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
+            // models with wave-wide roots (common.h): both roots by every lane, before the guard (the loads were clamped)
+            float a1w = 0.0f, s1w = 0.0f;
+            if constexpr (SQ::WAVE_WIDE && UPDATE) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                const float dcol = sq.dist_all(sq_lanes, dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]),
+                                                                      cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]), cx.nc));
+                const float a0 = g.a0[q], s0 = g.s0[q];
+                a1w = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);                             // :711
+                const float e = __fsub_rn(dcol, a0);
+                const float it = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
+                s1w = sq.all(sq_lanes, it < 0.0f ? 0.0f : it);                                      // :735-738
+            }
             if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]);
                 const float cross = cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]);   // shared by dis[j][cur] and dis[cur][j]
-                if constexpr (SQ::BATCHED && UPDATE) {
-                    avg[j] = a1b[q];
-                    sd[j] = s1b[q];
+                if constexpr (SQ::WAVE_WIDE && UPDATE) {
+                    avg[j] = a1w;
+                    sd[j] = s1w;
                 } else if (UPDATE) {
                     const float dcol = sq.dist(dgl_chain_sq(cross, nj, cx.nc));                       // dis[j][cur]
                     const float a0 = g.a0[q], s0 = g.s0[q];
@@ -346,10 +341,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(sq.dist(ckey), c, kl, &rank);
+        const bool pick = wave_pick_k(sq.dist_all(sq_lanes, ckey), c, kl, &rank);
+        float fw[CVRP_F];
+        if constexpr (SQ::WAVE_WIDE) cvrp_row<D3, true>(sq, cx, p, dm, av, sv, fw, sq_lanes);   // the rows' roots by every lane
         if (pick || anchor_early) {
             float *f = tileL + (pick ? rank : kl) * DGL_TILE_STRIDE;
-            cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
+            if constexpr (SQ::WAVE_WIDE) {
+#pragma unroll
+                for (int e = 0; e < CVRP_F; ++e) f[e] = fw[e];
+            } else {
+                cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
+            }
             if (pick) {
                 il[rank] = cj;
                 finish_last(f, rank);
@@ -385,10 +387,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const float2 p = xy2[jl];
         const float dm = cx.demb[jl], av = avg[jl], sv = sd[jl];
         int rank;
-        const bool pick = wave_pick_k(sq.dist(ckey), c, kd, &rank);
+        const bool pick = wave_pick_k(sq.dist_all(sq_lanes, ckey), c, kd, &rank);
+        float fw[CVRP_F], d0w = 0.0f;
+        if constexpr (SQ::WAVE_WIDE) d0w = cvrp_row<D3, true>(sq, cx, p, dm, av, sv, fw, sq_lanes);   // the rows' roots by every lane
         if (pick || anchor_early) {
             float *f = tileD + (pick ? rank : kd) * DGL_TILE_STRIDE;
-            const float d0 = cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
+            float d0 = d0w;
+            if constexpr (SQ::WAVE_WIDE) {
+#pragma unroll
+                for (int e = 0; e < CVRP_F; ++e) f[e] = fw[e];
+            } else {
+                d0 = cvrp_row<D3>(sq, cx, p, dm, av, sv, f);
+            }
             if (pick) {
                 id[rank] = cj;
                 f[3] = d0;
@@ -502,11 +512,11 @@ extern "C" int dgl_cvrp_reset(const dgl_cvrp_state_t *st, dgl_stream_t stream) {
     const int M = st->N + 1;
     size_t lds = (size_t)M * (st->demand_in_distance ? 3 : 2) * sizeof(float);
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset", st->N);
-    if (const uint16_t *tab = dgl_sqrt_table()) {
+    if (dgl_sqrt_reference_bits()) {
         if (lds > 48 * 1024)
             dgl_max_dynamic_lds((const void *)cvrp_reset_torch_kernel, (int)lds);
         hipLaunchKernelGGL(cvrp_reset_torch_kernel, dim3((M + 7) / 8, st->B), dim3(256), lds, (hipStream_t)stream, *st,
-                           DglSqrtMkl{tab});
+                           DglSqrtMkl{});
         DGL_CHECK_LAUNCH("dgl_cvrp_reset");
         return DGL_OK;
     }
@@ -586,15 +596,15 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
                             int32_t *idx_last_out, int32_t *idx_depot_out, uint8_t *infeasible_out, float *tile_out,
                             dgl_stream_t stream, const char *what, const CvrpBeamLink &link = CvrpBeamLink{}) {
     if (st->N + 1 <= DGL_DIRECT_MAX_POINTS) {
-        if (const uint16_t *tab = dgl_sqrt_table())
+        if (dgl_sqrt_reference_bits())
             return launch_cvrp_step_small<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
-                                                      tile_out, stream, what, link, DglSqrtMklT<true>{tab});
+                                                      tile_out, stream, what, link, DglSqrtMklT<true>{});
         return launch_cvrp_step_small<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                                   tile_out, stream, what, link, DglSqrtIeeeT<true>{});
     }
-    if (const uint16_t *tab = dgl_sqrt_table())
+    if (dgl_sqrt_reference_bits())
         return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
-                                               tile_out, stream, what, link, DglSqrtMkl{tab});
+                                               tile_out, stream, what, link, DglSqrtMkl{});
     return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                            tile_out, stream, what, link, DglSqrtIeee{});
 }
@@ -698,11 +708,11 @@ extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float 
         else
             hipLaunchKernelGGL((cvrp_state_data_kernel<false, SQ>), grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, sq);
     };
-    const uint16_t *tab = dgl_sqrt_table();
+    const bool tab = dgl_sqrt_reference_bits();
     if (st->N + 1 <= DGL_DIRECT_MAX_POINTS) {
-        if (tab) go(DglSqrtMklT<true>{tab}); else go(DglSqrtIeeeT<true>{});
+        if (tab) go(DglSqrtMklT<true>{}); else go(DglSqrtIeeeT<true>{});
     } else {
-        if (tab) go(DglSqrtMkl{tab}); else go(DglSqrtIeee{});
+        if (tab) go(DglSqrtMkl{}); else go(DglSqrtIeee{});
     }
     DGL_CHECK_LAUNCH("dgl_cvrp_state_data");
     return DGL_OK;

@@ -91,6 +91,9 @@ extern "C" int dgl_tsp_greedy_decode(const dgl_tsp_state_t *st, const float *pac
     // dgl_direct_sq): smaller instances take dgl_tsp_step + dgl_policy_forward
     if (st->N <= DGL_DIRECT_MAX_POINTS)
         return dgl_set_error(DGL_ERR_UNSUPPORTED, "N=%d: the fused decode takes instances of more than 25 points", st->N);
+    // ... and correctly rounded roots only
+    if (dgl_sqrt_reference_bits())
+        return dgl_set_error(DGL_ERR_UNSUPPORTED, "the fused decode takes correctly rounded square roots: dgl_set_sqrt_model(DGL_SQRT_IEEE) first");
     DGL_CHECK_ARG(st->xy && st->avg && st->sd && st->visited && st->tour, "NULL state buffer");
     DGL_CHECK_ARG(t_done >= 1 && t_done <= t_end && t_end <= st->N, "steps [%d, %d) outside [1, N=%d]", t_done, t_end, st->N);
     DGL_CHECK_ARG(io->problem == DGL_PROBLEM_TSP && io->R == st->R && io->N == st->N, "io does not describe this state");

@@ -92,17 +92,25 @@ __global__ __launch_bounds__(256) void tsp_permute_kernel(dgl_tsp_state_t src, d
 }
 
 // ------------------------------------------------------------------ square-root model check
+// whole waves take the model's wave-wide root (common.h), the ragged tail the one that works under any lane mask
 template <class SQ>
 __global__ void sqrt_apply_kernel(const float *__restrict__ x, float *__restrict__ out, long long n, SQ sq) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = sq(x[i]);
+    const typename SQ::Lanes ln = sq.lanes();
+    for (long long w0 = blockIdx.x * (long long)blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = w0 + (threadIdx.x & 63u);
+        if (w0 + 64 <= n)
+            out[i] = sq.all(ln, x[i]);
+        else if (i < n)
+            out[i] = sq(x[i]);
+    }
 }
 
 extern "C" int dgl_sqrt_apply(const float *x, float *out, int64_t n, dgl_stream_t stream) {
     DGL_CHECK_ARG(x != nullptr && out != nullptr && n >= 0, "NULL argument or n < 0");
     if (n == 0) return DGL_OK;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    if (const uint16_t *tab = dgl_sqrt_table())
-        hipLaunchKernelGGL(sqrt_apply_kernel<DglSqrtMkl>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, DglSqrtMkl{tab});
+    if (dgl_sqrt_reference_bits())
+        hipLaunchKernelGGL(sqrt_apply_kernel<DglSqrtMkl>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, DglSqrtMkl{});
     else
         hipLaunchKernelGGL(sqrt_apply_kernel<DglSqrtIeee>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, DglSqrtIeee{});
     DGL_CHECK_LAUNCH("dgl_sqrt_apply");
@@ -125,11 +133,11 @@ extern "C" int dgl_tsp_reset(const dgl_tsp_state_t *st, dgl_stream_t stream) {
     DGL_CHECK_ARG(lds <= 150 * 1024, "N=%d too large for the LDS-staged reset (max 19200)", st->N);
     if (lds > 48 * 1024)
         dgl_max_dynamic_lds((const void *)tsp_reset_kernel, (int)lds);
-    if (const uint16_t *tab = dgl_sqrt_table()) {
+    if (dgl_sqrt_reference_bits()) {
         if (lds > 48 * 1024)
             dgl_max_dynamic_lds((const void *)tsp_reset_torch_kernel, (int)lds);
         hipLaunchKernelGGL(tsp_reset_torch_kernel, dim3((st->N + 7) / 8, st->B), dim3(256), lds, (hipStream_t)stream, *st,
-                           DglSqrtMkl{tab});
+                           DglSqrtMkl{});
         DGL_CHECK_LAUNCH("dgl_tsp_reset");
         return DGL_OK;
     }
@@ -210,12 +218,12 @@ template <bool UPDATE>
 static int launch_tsp_step(const dgl_tsp_state_t *st, const int32_t *selected, int32_t t, int32_t knn, int32_t *idx_out,
                            float *tile_out, dgl_stream_t stream, const char *what, const TspBeamLink &link = TspBeamLink{}) {
     if (st->N <= DGL_DIRECT_MAX_POINTS) {
-        if (const uint16_t *tab = dgl_sqrt_table())
-            return launch_tsp_step_small<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMklT<true>{tab});
+        if (dgl_sqrt_reference_bits())
+            return launch_tsp_step_small<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMklT<true>{});
         return launch_tsp_step_small<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtIeeeT<true>{});
     }
-    if (const uint16_t *tab = dgl_sqrt_table())
-        return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMkl{tab});
+    if (dgl_sqrt_reference_bits())
+        return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtMkl{});
     return launch_tsp_step_sq<UPDATE>(st, selected, t, knn, idx_out, tile_out, stream, what, link, DglSqrtIeee{});
 }
 
@@ -285,13 +293,13 @@ extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *d
     DGL_CHECK_ARG(data_out != nullptr, "data_out is NULL");
     DGL_CHECK_ARG(t >= 1 && t <= st->N, "t=%d outside [1,N=%d]", t, st->N);
     dim3 grid(min((st->N + 255) / 256, 64), st->R);
-    const uint16_t *tab = dgl_sqrt_table();
+    const bool tab = dgl_sqrt_reference_bits();
     if (st->N <= DGL_DIRECT_MAX_POINTS && tab)
-        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMklT<true>>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMklT<true>{tab});
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMklT<true>>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMklT<true>{});
     else if (st->N <= DGL_DIRECT_MAX_POINTS)
         hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtIeeeT<true>>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtIeeeT<true>{});
     else if (tab)
-        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMkl>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMkl{tab});
+        hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtMkl>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtMkl{});
     else
         hipLaunchKernelGGL(tsp_state_data_kernel<DglSqrtIeee>, grid, dim3(256), 0, (hipStream_t)stream, *st, t, data_out, DglSqrtIeee{});
     DGL_CHECK_LAUNCH("dgl_tsp_state_data");

@@ -16,14 +16,20 @@ struct TspRowCtx {
 
 // raw feature row of a node at p with running statistics (a, sd): x, y, d(j,cur), avg, sd and
 // sin/cos of the direction towards the start node (TSP/TSPEnv.py:371,393,415,430-475)
-template <class SQ>
-__device__ __forceinline__ void tsp_row(const SQ &sq, const TspRowCtx &cx, float2 p, float a, float sd, float *f) {
+// ALL: called by all 64 lanes of the wave together (the model's wave-wide roots, common.h)
+template <bool ALL = false, class SQ>
+__device__ __forceinline__ void tsp_row(const SQ &sq, const TspRowCtx &cx, float2 p, float a, float sd, float *f,
+                                        const typename SQ::Lanes &ln = typename SQ::Lanes{}) {
     const float nj = dgl_sqnorm_t<SQ::DIRECT>(p.x, p.y);
-    const float ds = dgl_chain_dist(sq, p.x, p.y, nj, cx.xs, cx.ys, cx.ns);       // d(j, start)
+    auto dist = [&](float xj, float yj, float n2) {
+        const float r2 = dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(p.x, p.y, xj, yj), nj, n2);
+        return ALL ? sq.dist_all(ln, r2) : sq.dist(r2);
+    };
+    const float ds = dist(cx.xs, cx.ys, cx.ns);                                    // d(j, start)
     const float den = __fadd_rn(ds, 1e-7f);
     f[0] = p.x;
     f[1] = p.y;
-    f[2] = dgl_chain_dist(sq, p.x, p.y, nj, cx.xc, cx.yc, cx.nc);              // d(j, current)
+    f[2] = dist(cx.xc, cx.yc, cx.nc);                                              // d(j, current)
     f[3] = a;
     f[4] = sd;
     f[5] = __fdiv_rn(__fsub_rn(cx.ys, p.y), den);
@@ -126,6 +132,7 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
     };
     Group nxt;
     request(j_begin, nxt);
+    const typename SQ::Lanes sq_lanes = sq.lanes();         // (all 64 lanes are active here and at the top of the scan loop)
     // The current node and its coordinates are two dependent round trips; they start only now, behind the first
     // group's loads, which do not depend on them.  Wave-uniform values: kept in scalar registers.
     // (clamped: a node id outside [0, N) from a faulty caller must not turn into a wild address)
@@ -140,31 +147,26 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
-        // models that take their roots in batches (common.h, BATCHED): both roots of all chunks of the group first
-        float a1b[STEP_UNROLL], s1b[STEP_UNROLL];
-        if constexpr (SQ::BATCHED && UPDATE) {
-            float rad[STEP_UNROLL], dcolb[STEP_UNROLL], item[STEP_UNROLL];
-#pragma unroll
-            for (int q = 0; q < STEP_UNROLL; ++q) {
-                const float x = g.p[q].x, y = g.p[q].y;
-                rad[q] = dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y), dgl_sqnorm_t<SQ::DIRECT>(x, y), cx.nc);
-            }
-            sq.roots(rad, dcolb, true);
-#pragma unroll
-            for (int q = 0; q < STEP_UNROLL; ++q)
-                dgl_update_moments_item<false>(dcolb[q], g.a0[q], g.s0[q], up1, du, &a1b[q], &item[q]);
-            sq.roots(item, s1b, false);
-        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
+            // models with wave-wide roots (common.h): both roots by every lane, before the guard (the loads were clamped)
+            float a1w = 0.0f, s1w = 0.0f;
+            if constexpr (SQ::WAVE_WIDE && UPDATE) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                const float dcol = sq.dist_all(sq_lanes, dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y),
+                                                                      dgl_sqnorm_t<SQ::DIRECT>(x, y), cx.nc));
+                float item;
+                dgl_update_moments_item<false>(dcol, g.a0[q], g.s0[q], up1, du, &a1w, &item);
+                s1w = sq.all(sq_lanes, item);
+            }
             if (j < j_end) {
                 const float x = g.p[q].x, y = g.p[q].y, nj = dgl_sqnorm_t<SQ::DIRECT>(x, y);
                 const float cross = dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y);     // shared by dis[j][cur] and dis[cur][j]
                 float a1 = 0.0f, s1 = 0.0f;
-                if constexpr (SQ::BATCHED && UPDATE) {
-                    a1 = a1b[q];
-                    s1 = s1b[q];
+                if constexpr (SQ::WAVE_WIDE && UPDATE) {
+                    a1 = a1w;
+                    s1 = s1w;
                     if (QUIET) {
                     } else if (STREAM) {
                         __builtin_nontemporal_store(a1, avg + j);
@@ -273,9 +275,19 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         float av, sv;
         if (mom) { const float2 m = mom[jl]; av = m.x; sv = m.y; } else { av = avg[jl]; sv = sd[jl]; }
         int rank;
-        const bool pick = wave_pick_k(sq.dist(ckey), c, k, &rank);
+        const bool pick = wave_pick_k(sq.dist_all(sq_lanes, ckey), c, k, &rank);
         if (pick) idx_row[rank] = cj;
-        if (pick || anchor_early) tsp_row(sq, cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
+        if constexpr (SQ::WAVE_WIDE) {                      // the rows' roots by every lane, stored by those that hold one
+            float f[TSP_F];
+            tsp_row<true>(sq, cx, p, av, sv, f, sq_lanes);
+            if (pick || anchor_early) {
+                float *dst = tile + (pick ? rank : k) * DGL_TILE_STRIDE;
+#pragma unroll
+                for (int e = 0; e < TSP_F; ++e) dst[e] = f[e];
+            }
+        } else if (pick || anchor_early) {
+            tsp_row(sq, cx, p, av, sv, tile + (pick ? rank : k) * DGL_TILE_STRIDE);
+        }
         if (c == 64 && lane == 63) tsp_features(sq, st, cx, cur, tile + k * DGL_TILE_STRIDE);
     } else {
         wave_select_general(sq, keys, N, k, scratch, [&](int j, int rank) {

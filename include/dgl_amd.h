@@ -63,20 +63,21 @@ DGL_API const char *dgl_last_error_string(void);
  * inputs; the running standard deviations amplify such last-bit differences by N / #unvisited and the min-max
  * normalisation by another hundredfold, so the last decisions of a tour can depend on them.  No counterpart in the
  * reference's own interface: it selects which of the two the state kernels (reset, step, knn, state_data) reproduce.
- *   DGL_SQRT_IEEE        correctly rounded roots (default; what torch without MKL, or on another CPU path, computes up
- *                        to its own library's rounding); the reset's means are binary64 sums rounded once.
  *   DGL_SQRT_MKL_AVX512  MKL's AVX-512 float sqrt bit for bit, and the reset's means in torch.mean's own summation
- *                        order (8-lane cascade sum).  rsqrt14_table: VRSQRT14 over [1, 4) as 2^16 uint16 on the
- *                        current device, index = exponent parity << 15 | mantissa >> 8, value = (estimate's bits -
- *                        0x3F000000) >> 7 (the estimate depends on no lower mantissa bit; exact powers of 4 are
- *                        special-cased; dgl_amd/sqrt_model.py builds it from dgl_amd/data/rsqrt14_avx512.npz), owned by
- *                        the caller and kept alive while the model is set.  Step kernels 2-3 us slower per launch.
+ *                        order (8-lane cascade sum): the device then carries the reference's state to the last bit.
+ *                        The default.  VRSQRT14 is evaluated in closed form - over [1, 4) the instruction is piecewise
+ *                        linear in the mantissa, 64 segments with one pair of integers each, compiled into the kernels
+ *                        (csrc/common.h; solved from a recording of the instruction over all 2^24 inputs of [1, 4),
+ *                        dgl_amd/data/rsqrt14_avx512.npz) - so the model needs nothing from the caller.
+ *   DGL_SQRT_IEEE        correctly rounded roots (what torch without MKL, or on another CPU path, computes up to its
+ *                        own library's rounding); the reset's means are binary64 sums rounded once.  Step kernels up
+ *                        to 4 % faster at saturating batches, rollouts about 1 %.
  * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to.
- * The library starts with DGL_SQRT_IEEE (the other model needs the caller's table); the Python host (dgl_amd/sqrt_model.py)
- * selects DGL_SQRT_MKL_AVX512 on every device it creates an engine on unless the environment says DGL_SQRT_MODEL=ieee. */
+ * The Python host (dgl_amd/sqrt_model.py) sets it on every device it creates an engine on (environment: DGL_SQRT_MODEL=ieee
+ * or mkl_avx512).  dgl_tsp_greedy_decode implements DGL_SQRT_IEEE only and refuses to run under the other model. */
 #define DGL_SQRT_IEEE 0
 #define DGL_SQRT_MKL_AVX512 1
-DGL_API int dgl_set_sqrt_model(int32_t model, const uint16_t *rsqrt14_table);
+DGL_API int dgl_set_sqrt_model(int32_t model);
 /* out[i] = the model's square root of x[i]: what torch.sqrt returns for x[i] under the model (the root the reference
  * takes at TSP/TSPEnv.py:409 and CVRP/CVRPEnv.py:738), for checking a model against recorded torch.sqrt values. */
 DGL_API int dgl_sqrt_apply(const float *x, float *out, int64_t n, dgl_stream_t stream);

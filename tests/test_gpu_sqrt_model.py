@@ -146,7 +146,8 @@ def test_cvrp_state_bit_for_bit_along_the_reference_route(name, device, mkl):
 
 
 def test_square_roots_follow_the_recorded_instruction_on_random_inputs(device, mkl):
-    """dgl_sqrt_apply against the NumPy restatement of MKL's AVX-512 float sqrt over the recorded VRSQRT14 table
+    """dgl_sqrt_apply (the kernels' closed form of VRSQRT14) against the NumPy restatement of MKL's AVX-512 float sqrt
+    over the recording of the instruction
     (tools/make_rsqrt14_table.py::model_sqrt, itself equal to torch.sqrt on the fixture above): four million inputs
     over sixty binades, the exact powers of two and four among them."""
     import sys
@@ -160,3 +161,15 @@ def test_square_roots_follow_the_recorded_instruction_on_random_inputs(device, m
     got = mkl.apply(torch.from_numpy(x).to(device)).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert (want != np.sqrt(x)).mean() > 0.003
+    # whole waves take the closed form through the lanes' registers, a ragged tail through memory: 63 inputs are all tail
+    for lo in range(0, 63 * 50, 63):
+        got = mkl.apply(torch.from_numpy(x[lo:lo + 63].copy()).to(device)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want[lo:lo + 63].view(np.uint32))
+    # zeros, negative numbers, infinities and NaN: as under the other model
+    odd = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, -1e-30, 2.0, 0.0, 3.0] * 13, np.float32)
+    with np.errstate(invalid="ignore"):
+        want_odd = np.where((odd == 2.0) | (odd == 3.0), model_sqrt(odd, rsqrt14_table_full()), np.sqrt(odd))
+    for part in (odd, odd[:50]):                        # (two whole waves and two lanes / a ragged wave)
+        got = mkl.apply(torch.from_numpy(part.copy()).to(device)).cpu().numpy()
+        ok = (got.view(np.uint32) == want_odd[:part.size].view(np.uint32)) | (np.isnan(got) & np.isnan(want_odd[:part.size]))
+        assert ok.all(), (part[~ok], got[~ok])

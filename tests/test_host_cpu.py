@@ -183,3 +183,21 @@ def test_multistep_lr_follows_torch_on_a_fresh_run_and_on_resume():
         opt2.step(); ref2.step(); mine2.step()
         assert abs(tr2.lr - opt2.param_groups[0]["lr"]) <= 1e-12 * base
     assert abs(tr2.lr - saved_lr * gamma ** 3) <= 1e-12 * base
+
+
+def test_rsqrt14_segment_constants_reproduce_the_recorded_instruction():
+    """The 64 integer pairs compiled into the kernels (dgl_amd/csrc/common.h: DGL_RSQRT14_SEG) are the ones the recording
+    of VRSQRT14 determines - one fit per segment - and give back every one of its 2^16 distinct values."""
+    import re
+    from dgl_amd.sqrt_model import rsqrt14_segments, rsqrt14_table
+    table = rsqrt14_table()
+    seg = rsqrt14_segments(table)
+    src = open(os.path.join(os.path.dirname(GOLDEN), "..", "dgl_amd", "csrc", "common.h")).read()
+    body = src[src.index("DGL_RSQRT14_SEG[64] = {") + len("DGL_RSQRT14_SEG[64] = {"):]
+    compiled = np.array([int(v) for v in re.findall(r"-?\d+", body[:body.index("};")])], np.int64).reshape(64, 2)
+    assert np.array_equal(compiled, seg)
+    # the kernels' evaluation, for all 2^16 (parity, upper mantissa) classes: index (bits >> 18) & 63, m = bits 17..8
+    cls = np.arange(1 << 16, dtype=np.int64)                  # parity << 15 | mantissa >> 8
+    bits = ((1 - (cls >> 15)) << 23) | ((cls & 0x7FFF) << 8)  # a float's low 24 bits with that parity and mantissa
+    c, ns = compiled[(bits >> 18) & 63].T
+    assert np.array_equal((c + ns * ((bits >> 8) & 1023)) >> 9, table.astype(np.int64))
