@@ -174,9 +174,6 @@ struct DglSqrtMklT {
     __device__ __forceinline__ static bool ordinary(float x) { return __builtin_amdgcn_classf(x, 0x140); }
     // the model's root of x; all 64 lanes active
     __device__ __forceinline__ float all(const Lanes &ln, float x) const {
-#ifdef DGL_MKL_FAKE
-        return dgl_sqrt(x);
-#endif
         const int addr = (int)((__float_as_uint(x) >> 16) & 0xFCu);
         const int c = __builtin_amdgcn_ds_bpermute(addr, ln.c), ns = __builtin_amdgcn_ds_bpermute(addr, ln.ns);
         float out = refine(x, c, ns);
