@@ -2,9 +2,11 @@
 table, run-length encoded, to dgl_amd/data/rsqrt14_avx512.npz.  Needs gcc and a CPU with AVX-512F (the instruction's
 result is architecturally defined: every AVX-512 CPU returns the same bits).
 
-The decode kernels' optional square-root model "mkl_avx512" uses the table to reproduce, bit for bit, what torch.sqrt and
-torch.cdist return on CPU when torch is built against MKL and runs on an AVX-512 machine (the container the golden
-vectors were made in): MKL's vector sqrt refines the 14-bit estimate y = rsqrt14(x) once,
+The decode kernels' square-root model "mkl_avx512" reproduces, bit for bit, what torch.sqrt and torch.cdist return on
+CPU when torch is built against MKL and runs on an AVX-512 machine (the container the golden vectors were made in); the
+recording is what its constants were solved from (dgl_amd/sqrt_model.py::rsqrt14_segments: the instruction is piecewise
+linear, 64 segments with one integer pair each) and what the tests check them against.  MKL's vector sqrt refines the
+14-bit estimate y = rsqrt14(x) once,
     s = x y;  result = fma(fma(-s, s, x), y / 2, s),
 which is one ulp below the correctly rounded root on 0.6 % of all inputs.  The result of rsqrt14 has 16 significant
 bits and scales exactly with the exponent, so a 16-bit table over two binades describes it completely.  The script
