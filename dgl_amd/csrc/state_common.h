@@ -1,5 +1,6 @@
 // Pieces shared by the TSP and CVRP state kernels.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // Row mean / population std of the pairwise distance matrix of one instance, without
@@ -129,7 +130,10 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
     const float xi = pts[ii].x, yi = pts[ii].y, zi = z ? lds_z[ii] : 0.0f;
     const float ni = z ? __fadd_rn(dgl_sqnorm(xi, yi), __fmul_rn(zi, zi)) : dgl_sqnorm(xi, yi);
     const bool direct = M <= DGL_DIRECT_MAX_POINTS;            // (common.h, dgl_direct_sq: correctly rounded roots there)
-    auto dist = [&](int j) {
+    // ALL: called by all 64 lanes together (the model's wave-wide root, common.h): the interleaved part of the row
+    const typename SQ::Lanes ln = sq.lanes();
+    auto dist = [&](int j, auto all_lanes) {
+        constexpr bool ALL = decltype(all_lanes)::value;
         const float2 pj = pts[j];
         if (direct) {
             float d2 = dgl_direct_sq(xi, yi, pj.x, pj.y);
@@ -142,15 +146,18 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
             cross = __fmaf_rn(-2.0f * zi, zj, cross);
             nj = __fadd_rn(nj, __fmul_rn(zj, zj));
         }
-        return sq(dgl_chain_sq(cross, ni, nj));
+        const float r2 = dgl_chain_sq(cross, ni, nj);
+        return ALL ? sq.all(ln, r2) : sq(r2);
     };
+    const std::true_type together{};
+    const std::false_type alone{};
     const int vec_size = M / 8, size_ilp = vec_size / 4;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // cascade levels (level step 16 up to 2^19 vectors per accumulator)
     double s64 = 0.0, q64 = 0.0;
     int t = 0;
     while (t + 16 <= size_ilp) {
         for (int u = 0; u < 16; ++u, ++t) {
-            const float d = dist(32 * t + l);
+            const float d = dist(32 * t + l, together);
             a0 = __fadd_rn(a0, d);
             s64 += (double)d;
             q64 = fma((double)d, (double)d, q64);
@@ -162,7 +169,7 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
         }
     }
     for (; t < size_ilp; ++t) {
-        const float d = dist(32 * t + l);
+        const float d = dist(32 * t + l, together);
         a0 = __fadd_rn(a0, d);
         s64 += (double)d;
         q64 = fma((double)d, (double)d, q64);
@@ -171,7 +178,7 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
     // left-over vectors: accumulator 0 only
     for (int w = 4 * size_ilp; w < vec_size; ++w) {
         if (k == 0) {
-            const float d = dist(8 * w + v);
+            const float d = dist(8 * w + v, alone);
             a0 = __fadd_rn(a0, d);
             s64 += (double)d;
             q64 = fma((double)d, (double)d, q64);
@@ -185,7 +192,7 @@ __device__ __forceinline__ void dgl_reset_rows_torch(const float *__restrict__ x
     // scalar tail, then the eight lanes in order
     float total = 0.0f;
     for (int j = 8 * vec_size; j < M; ++j) {
-        const float d = dist(j);
+        const float d = dist(j, together);
         total = __fadd_rn(total, d);
         if (l == 0) { s64 += (double)d; q64 = fma((double)d, (double)d, q64); }
     }

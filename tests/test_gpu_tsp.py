@@ -204,6 +204,28 @@ def test_fused_greedy_decode_is_bit_identical(device, monkeypatch, ieee_roots):
     assert np.array_equal(ref_tour.cpu().numpy(), case["tour"][:33])
 
 
+def test_fused_greedy_decode_refuses_the_reference_bits_model(device, monkeypatch):
+    """The fused decode kernel's step phase takes correctly rounded roots only: under the default square-root model the
+    engine does not offer it, and the library refuses a direct call before anything is launched."""
+    import ctypes
+    from dgl_amd import sqrt_model
+    from dgl_amd.engine import PackedPolicy, TspEngine
+    from dgl_amd._lib import PROBLEM_TSP, stream_ptr, ptr
+    case, weights = load_golden("tsp_n100_b64_nn")
+    eng = TspEngine(torch.from_numpy(case["xy"][:4]).to(device), 1, 30)
+    pol = PackedPolicy(weights, PROBLEM_TSP, device)
+    sqrt_model.use("mkl_avx512", device)
+    monkeypatch.setenv("DGL_FUSED_DECODE", "1")
+    assert not eng.fused_decode_available()
+    eng.reset()
+    eng.step(torch.zeros(4, dtype=torch.int32, device=device))
+    io = eng.policy_io(want_logits=False, want_prob=False)
+    rc = eng.lib.dgl_tsp_greedy_decode(ctypes.byref(eng.state["struct"]), ptr(pol.packed), ctypes.byref(io), eng.t, eng.N,
+                                       eng.knn, stream_ptr())
+    assert rc == -2 and b"correctly rounded" in eng.lib.dgl_last_error_string()
+    sqrt_model.use(sqrt_model.default_model(), device)
+
+
 def test_fused_greedy_decode_odd_rows_long_instances(device, monkeypatch, ieee_roots):
     """An odd row count leaves the last workgroup of the fused decode with a spare pair of waves, which walks the last
     row without storing anything.  Rows of 2100 nodes keep several groups of loads in flight per wave (and take the
