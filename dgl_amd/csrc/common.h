@@ -83,19 +83,16 @@ __device__ __forceinline__ float dgl_sqrt_pk(float x) {
 // ---------------------------------------------------------------------------------------------- square-root models
 // Every square root on the decode path that the reference takes with torch.sqrt / torch.cdist (distance entries, the
 // running standard deviations) goes through a model object `sq`:
-//   DglSqrtIeee  the correctly rounded root (default);
+//   DglSqrtIeee  the correctly rounded root;
 //   DglSqrtMkl   what those torch calls return on a CPU build of torch linked against MKL that runs on an AVX-512 machine
-//                (where the golden vectors were captured): MKL's vector sqrt refines the instruction VRSQRT14's estimate
-//                y once, s = x y, result = fma(fma(-s, s, x), y / 2, s), which is the correctly rounded root or - on
-//                0.6 % of all inputs, whenever the exact root lies less than 0.06 ulp above the midpoint of two floats -
-//                the float below it.  `tab` holds VRSQRT14 over [1, 4): the instruction's estimate depends on the
-//                exponent's parity and the upper 15 mantissa bits only (measured over all 2^24 inputs of [1, 4),
-//                tools/make_rsqrt14_table.py), so the table has 2^16 entries of 16 bits, index = parity << 15 |
-//                mantissa >> 8 (128 KB: L2-resident); the exact powers of 4 are special-cased (estimate exactly 1);
-//                the estimate scales exactly with the exponent.
-//                Only inputs whose correctly rounded root was rounded up by more than 0.4 ulp can differ, so only those
-//                lanes look the estimate up.
-// sq(x): one root; sq.pk(x): the same value (the IEEE model evaluates its two residuals with one packed FMA there).
+//                (where the golden vectors were captured; the default, dgl_set_sqrt_model): MKL's vector sqrt refines
+//                the instruction VRSQRT14's estimate y once, s = x y, result = fma(fma(-s, s, x), y / 2, s), which is
+//                the correctly rounded root or - on 0.6 % of all inputs, whenever the exact root lies less than 0.06 ulp
+//                above the midpoint of two floats - the float below it.  The estimate is evaluated in closed form
+//                (DGL_RSQRT14_SEG below); it scales exactly with powers of 4.
+// sq(x): one root; sq.pk(x): the same value (the IEEE model evaluates its two residuals with one packed FMA there);
+// sq.all(ln, x) / sq.dist_all(ln, x): the same values again, for places where all 64 lanes of the wave are active (ln =
+// sq.lanes(), taken where they are: see DglSqrtMklT).
 // ULPS: how far above a bound on radicands a radicand can lie and still have a root that ties with the bound's.
 // DIRECT (instances of at most 25 points, see dgl_direct_sq): distance roots are the correctly rounded ones under
 // every model - torch.cdist takes them with the scalar sqrt there; sq.dist(x) / sq.dist_pk(x) are the roots of distance
