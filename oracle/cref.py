@@ -40,4 +40,25 @@ def load() -> ctypes.CDLL:
     lib.dglref_tsp_length.restype = ctypes.c_double
     lib.dglref_cvrp_length.argtypes = [f32p, i32p, i8p, ci]
     lib.dglref_cvrp_length.restype = ctypes.c_double
+    lib.dglref_set_rsqrt14.argtypes = [ctypes.c_void_p]
+    lib.dglref_model_sqrt.argtypes = [f32p, ci, f32p]
     return lib
+
+
+_table = None          # the VRSQRT14 recording the library points at (kept alive here)
+
+
+def use_model(lib: ctypes.CDLL, model: str) -> None:
+    """Which square root the distance and variance roots of `lib` stand for: "ieee" (correctly rounded, the state after
+    load()) or "mkl_avx512" (MKL's AVX-512 float sqrt, looked up in the recording of VRSQRT14 that ships as
+    dgl_amd/data/rsqrt14_avx512.npz).  Process-wide: callers switch back to "ieee" when they are done."""
+    global _table
+    if model == "ieee":
+        lib.dglref_set_rsqrt14(None)
+        return
+    if model != "mkl_avx512":
+        raise ValueError(model)
+    if _table is None:
+        from dgl_amd.sqrt_model import rsqrt14_table
+        _table = np.ascontiguousarray(rsqrt14_table())
+    lib.dglref_set_rsqrt14(_table.ctypes.data)

@@ -41,16 +41,45 @@
 
 static inline float sqnorm(float x, float y) { return x * x + y * y; }
 
+/* Which square root torch.sqrt / torch.cdist's final root stand for.  NULL (the default): the correctly rounded root.
+ * Otherwise the root a CPU build of torch linked against MKL returns on an AVX-512 machine - the setting the golden
+ * vectors were captured under: MKL refines the instruction VRSQRT14's estimate y once, s = x y, result =
+ * fma(fma(-s, s, x), y / 2, s).  `table` is the recording of that instruction over [1, 4) reduced to 2^16 entries
+ * (index = exponent parity << 15 | mantissa >> 8, value = (estimate's bits - 0x3F000000) >> 7; the estimate depends on no
+ * lower mantissa bit, is exactly 1 for the exact powers of 4 and scales exactly with powers of 4), as
+ * dgl_amd/sqrt_model.py::rsqrt14_table expands it from dgl_amd/data/rsqrt14_avx512.npz; the caller keeps it alive.
+ * This restatement looks the estimate up in the recording; the device library evaluates it from constants. */
+static const uint16_t *g_rsqrt14 = NULL;
+DGLREF_API void dglref_set_rsqrt14(const uint16_t *table) { g_rsqrt14 = table; }
+
+static float model_sqrtf(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if (g_rsqrt14 == NULL || b == 0u || b >= 0x7F800000u || b < 0x00800000u) return sqrtf(x);   /* 0, negative, inf, NaN, denormal */
+    int e = (int)(b >> 23) - 127, p = e & 1, q = (e - p) / 2;
+    uint32_t mant = b & 0x7FFFFFu;
+    uint32_t yb = (p == 0 && mant == 0u) ? 0x3F800000u : 0x3F000000u + ((uint32_t)g_rsqrt14[((uint32_t)p << 15) | (mant >> 8)] << 7);
+    yb -= (uint32_t)q << 23;
+    float y;
+    memcpy(&y, &yb, 4);
+    float s = x * y, h = 0.5f * y;
+    return fmaf(fmaf(-s, s, x), h, s);
+}
+/* out[i] = the selected model's root of x[i] */
+DGLREF_API void dglref_model_sqrt(const float *x, int n, float *out) {
+    for (int i = 0; i < n; ++i) out[i] = model_sqrtf(x[i]);
+}
+
 /* d(i, j) of the matrix-product form of cdist: i is the ROW (query), j the column. */
 static inline float chain_dist(float xi, float yi, float ni, float xj, float yj, float nj) {
     float acc = (-2.0f * xi) * xj;
     acc = fmaf(-2.0f * yi, yj, acc);
     acc = acc + ni;
     acc = acc + nj;
-    return sqrtf(acc > 0.0f ? acc : 0.0f);
+    return model_sqrtf(acc > 0.0f ? acc : 0.0f);
 }
 
-/* the per-pair form cdist takes for at most DIRECT_MAX_POINTS points */
+/* the per-pair form cdist takes for at most DIRECT_MAX_POINTS points (the scalar sqrt: correctly rounded under either model) */
 #define DIRECT_MAX_POINTS 25
 static inline float direct_dist(float xi, float yi, float xj, float yj) {
     float dx = xi - xj, dy = yi - yj;
@@ -160,7 +189,7 @@ DGLREF_API void dglref_step_features(const float *xy, int m, int cur, int u, int
         float e = d - a0;
         float item = (sd[j] * sd[j] * up1 - e * e) / uf;
         if (clamp && item < 0.0f) item = 0.0f;
-        sd[j] = sqrtf(item);
+        sd[j] = model_sqrtf(item);
     }
 }
 

@@ -155,11 +155,31 @@ def test_recurrences_bit_exact_vs_c_oracle(device, ieee_roots, N, knn, kd, until
     _recurrences_vs_c_oracle(device, N, knn, kd, until)
 
 
-def _recurrences_vs_c_oracle(device, N, knn, kd, until, seed=3, B=2):
-    """(correctly rounded roots must be selected by the caller: the plain-C oracle takes them)"""
-    from dgl_amd.engine import CvrpEngine
+@pytest.mark.parametrize("N,knn,kd,until", [(25, 8, 8, None), (150, 15, 20, None), (700, 15, 20, 60), (1000, 50, 50, 30),
+                                            (2500, 15, 15, 40), (5000, 100, 100, 10)])
+def test_recurrences_under_the_reference_bits_model(device, ieee_roots, N, knn, kd, until):
+    """The same comparison under the default square-root model, the C oracle looking MKL's estimate up in the recording
+    of the instruction (26 points with the depot: the first size with matrix-product distances)."""
+    _recurrences_vs_c_oracle(device, N, knn, kd, until, seed=N, model="mkl_avx512")
+
+
+def _recurrences_vs_c_oracle(device, N, knn, kd, until, seed=3, B=2, model="ieee"):
+    """model: the square-root model of both sides (dgl_amd/sqrt_model.py, oracle/cref.py::use_model); the device is left
+    with correctly rounded roots selected."""
+    from dgl_amd import sqrt_model
     from oracle import cref
     lib = cref.load()
+    sqrt_model.use(model, device)
+    cref.use_model(lib, model)
+    try:
+        _compare_recurrences(lib, device, N, knn, kd, until, seed, B)
+    finally:
+        cref.use_model(lib, "ieee")
+        sqrt_model.use("ieee", device)
+
+
+def _compare_recurrences(lib, device, N, knn, kd, until, seed, B):
+    from dgl_amd.engine import CvrpEngine
     rng = np.random.default_rng(seed)
     M = N + 1
     xy = rng.random((B, M, 2), dtype=np.float32)

@@ -1,4 +1,6 @@
 """Pins the plain-C restatement (oracle/dgl_ref.c) against torch and the golden vectors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,3 +152,27 @@ def test_chain_cdist_restates_torch_cdist():
         assert float(diff.float().mean()) < 0.02, float(diff.float().mean())
         assert int(ulp[(ref > 1e-3) & (got > 1e-3)].max()) <= 1
         assert torch.equal(ref == 0, got == 0)
+
+
+def test_reference_bits_root_equals_recorded_torch_sqrt():
+    """The C oracle's second square-root model (MKL's AVX-512 root, the estimate looked up in the recording of VRSQRT14)
+    against torch.sqrt values recorded on the machine the golden vectors were captured on; the default stays the
+    correctly rounded root."""
+    from conftest import GOLDEN
+    from oracle import cref
+    lib = cref.load()
+    g = np.load(os.path.join(GOLDEN, "torch_sqrt_mkl.npz"))
+    x = np.ascontiguousarray(g["x"])
+    out = np.empty_like(x)
+    lib.dglref_model_sqrt(x, x.size, out)
+    assert np.array_equal(out, np.sqrt(x))
+    cref.use_model(lib, "mkl_avx512")
+    try:
+        lib.dglref_model_sqrt(x, x.size, out)
+        assert np.array_equal(out.view(np.uint32), g["sqrt"].view(np.uint32))
+        edge = np.array([0.0, 1.0, 4.0, 0.25, 2.0, np.inf], np.float32)
+        res = np.empty_like(edge)
+        lib.dglref_model_sqrt(edge, edge.size, res)
+        assert np.array_equal(res[[0, 1, 2, 3, 5]], np.array([0.0, 1.0, 2.0, 0.5, np.inf], np.float32))
+    finally:
+        cref.use_model(lib, "ieee")

@@ -4,7 +4,9 @@ random and checks
     knn = 1 ... 120, 1 ... 5 rows, whole tours for short instances and prefixes for long ones;
   * the CVRP step kernel likewise (both neighbourhoods, capacities, feasibility);
   * the one-launch policy kernel for 33 ... 128 tokens against the general path, TSP and CVRP layouts.
-usage: python tools/stress_parity.py [seconds] [seed]      (correctly rounded roots: the C oracle's)"""
+Every step-kernel case draws its square-root model too: correctly rounded roots, or the reference-bits model with the C
+oracle looking MKL's estimate up in the recording of the instruction (oracle/cref.py::use_model).
+usage: python tools/stress_parity.py [seconds] [seed]"""
 import os, sys, time, types
 import numpy as np, torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -20,10 +22,11 @@ dev = torch.device('cuda:0')
 sqrt_model.use("ieee", dev)
 rng = np.random.default_rng(seed)
 t0 = time.time()
-done = {"tsp": 0, "cvrp": 0, "wide_tsp": 0, "wide_cvrp": 0}
+done = {"tsp": 0, "cvrp": 0, "wide_tsp": 0, "wide_cvrp": 0, "reference_bits": 0}
 last = t0
 while time.time() - t0 < budget:
     kind = rng.choice(["tsp", "tsp", "cvrp", "wide_tsp", "wide_cvrp"])
+    model = str(rng.choice(["ieee", "mkl_avx512"]))
     if kind == "tsp":
         N = int(rng.choice([rng.integers(2, 27), rng.integers(26, 200), rng.integers(200, 1200), rng.integers(1200, 3000)]))
         knn = int(rng.choice([1, 5, 15, 30, 31, 50, 64, 65, 100, 120]))
@@ -34,17 +37,17 @@ while time.time() - t0 < budget:
         order = np.stack([rng.permutation(N) for _ in range(B)])
         until = None if N <= 300 else int(rng.integers(20, 80))
         try:
-            K._run_case(dev, xy, order, knn, check_until=until)
+            K._run_case(dev, xy, order, knn, check_until=until, model=model)
         except AssertionError as e:
-            print("TSP MISMATCH", dict(N=N, knn=knn, B=B, until=until), str(e)[:300], flush=True); raise
+            print("TSP MISMATCH", dict(N=N, knn=knn, B=B, until=until, model=model), str(e)[:300], flush=True); raise
     elif kind == "cvrp":
         N = int(rng.choice([rng.integers(2, 26), rng.integers(25, 200), rng.integers(200, 1500)]))
         knn, kd = int(rng.choice([1, 8, 15, 30, 50, 100])), int(rng.choice([1, 8, 15, 30, 50, 100]))
         until = None if N <= 200 else int(rng.integers(20, 60))
         try:
-            C._recurrences_vs_c_oracle(dev, N, knn, kd, until, seed=int(rng.integers(1 << 30)), B=int(rng.integers(1, 4)))
+            C._recurrences_vs_c_oracle(dev, N, knn, kd, until, seed=int(rng.integers(1 << 30)), B=int(rng.integers(1, 4)), model=model)
         except AssertionError as e:
-            print("CVRP MISMATCH", dict(N=N, knn=knn, kd=kd, until=until), str(e)[:300], flush=True); raise
+            print("CVRP MISMATCH", dict(N=N, knn=knn, kd=kd, until=until, model=model), str(e)[:300], flush=True); raise
     elif kind == "wide_tsp":
         knn = int(rng.integers(32, 128))
         P.test_tsp_wide_kernel_agrees_with_general_path(knn, str(rng.choice(["random", "trained"])), dev)
@@ -54,6 +57,7 @@ while time.time() - t0 < budget:
             continue
         P.test_cvrp_wide_kernel_agrees_with_general_path(knn, kd, dev)
     done[kind] += 1
+    done["reference_bits"] += kind in ("tsp", "cvrp") and model == "mkl_avx512"
     if time.time() - last > 30:
         last = time.time()
         print(f"{time.time() - t0:.0f} s: {done}", flush=True)
