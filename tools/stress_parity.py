@@ -21,6 +21,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device('cuda:0')
 sqrt_model.use("ieee", dev)
 rng = np.random.default_rng(seed)
+from dgl_amd import _lib
+from dgl_amd.engine import PackedPolicy
+from dgl_amd.weights import load_checkpoint
+wide_policy = PackedPolicy(load_checkpoint(os.path.join(ROOT, "tests", "golden", "ckpt_tsp_nn.pt")), _lib.PROBLEM_TSP, dev)
 t0 = time.time()
 done = {"tsp": 0, "cvrp": 0, "wide_tsp": 0, "wide_cvrp": 0, "reference_bits": 0}
 last = t0
@@ -48,9 +52,18 @@ while time.time() - t0 < budget:
             C._recurrences_vs_c_oracle(dev, N, knn, kd, until, seed=int(rng.integers(1 << 30)), B=int(rng.integers(1, 4)), model=model)
         except AssertionError as e:
             print("CVRP MISMATCH", dict(N=N, knn=knn, kd=kd, until=until, model=model), str(e)[:300], flush=True); raise
-    elif kind == "wide_tsp":
+    elif kind == "wide_tsp" and rng.random() < 0.5:
         knn = int(rng.integers(32, 128))
         P.test_tsp_wide_kernel_agrees_with_general_path(knn, str(rng.choice(["random", "trained"])), dev)
+    elif kind == "wide_tsp":                                 # row counts from 1 up, instances barely larger than the neighbourhood
+        knn, R = int(rng.integers(32, 128)), int(rng.choice([1, 2, 3, int(rng.integers(4, 300))]))
+        N = int(rng.choice([knn + 2, knn + int(rng.integers(3, 60)), 400]))
+        eng = P._tsp_engine(R, N, knn, dev, seed=int(rng.integers(1 << 30)))
+        (la, pa, sa), (lb, pb, sb) = P._wide_vs_general(eng, wide_policy, knn + 1)
+        rel = float((np.abs(la - lb) / np.abs(lb).max(axis=1, keepdims=True)).max())
+        assert rel < 3e-5, ("WIDE MISMATCH", dict(R=R, N=N, knn=knn), rel)
+        np.testing.assert_allclose(pa, pb, rtol=5e-4 + 2 * float(np.abs(la - lb).max()), atol=1e-7)
+        assert (sa == sb).mean() >= 0.97 or R < 30, dict(R=R, N=N, knn=knn)
     else:
         kd = int(rng.integers(16, 64)); knn = int(rng.integers(8, kd + 1))      # the direct neighbourhood is never the wider one
         if knn + kd + 2 <= 32 or knn + kd + 2 > 128:
