@@ -478,6 +478,29 @@ __global__ __launch_bounds__(256) void cvrp_length_kernel(dgl_cvrp_state_t st, f
     if (lane == 0) out[r] = (float)s;
 }
 
+// The same length as the reference's torch build returns it (CVRP/CVRPEnv.py:991): both roots of a step through the
+// reference-bits model, added, and the steps summed in torch.sum's order (dgl_torch_row_sum).  Half a wave per row.
+__global__ __launch_bounds__(256) void cvrp_length_torch_kernel(dgl_cvrp_state_t st, float *__restrict__ out, DglSqrtMkl sq) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), r = min(row, st.R - 1);
+    const int N = st.N, M = N + 1;
+    const float *xyb = st.xy + (size_t)(r / st.rows_per_instance) * M * 2;
+    const int32_t *nodes = st.nodes + (size_t)r * N;
+    const int8_t *flags = st.flags + (size_t)r * N;
+    const DglSqrtMkl::Lanes ln = sq.lanes();
+    const float total = dgl_torch_row_sum(N, [&](int p, auto all_lanes) {
+        const int cur = min(max(nodes[p], 0), N), prev = min(max(nodes[p == 0 ? N - 1 : p - 1], 0), N);
+        const int mid = flags[p] ? 0 : cur;
+        const int mid2 = p == 0 ? 0 : mid;
+        auto sq2 = [&](int a, int c) {
+            const float dx = __fsub_rn(xyb[2 * a], xyb[2 * c]), dy = __fsub_rn(xyb[2 * a + 1], xyb[2 * c + 1]);
+            return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        };
+        const float a2 = sq2(cur, mid), b2 = sq2(prev, mid2);
+        return decltype(all_lanes)::value ? __fadd_rn(sq.all(ln, a2), sq.all(ln, b2)) : __fadd_rn(sq(a2), sq(b2));
+    });
+    if (row < st.R && (threadIdx.x & 31) == 0) out[row] = total;
+}
+
 // ------------------------------------------------------------------ beam permutation
 __global__ __launch_bounds__(256) void cvrp_permute_kernel(dgl_cvrp_state_t src, dgl_cvrp_state_t dst,
                                                           const int32_t *__restrict__ prev_k, int beam, int t) {
@@ -721,7 +744,10 @@ extern "C" int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float 
 extern "C" int dgl_cvrp_route_length(const dgl_cvrp_state_t *st, float *length_out, dgl_stream_t stream) {
     if (int e = check_cvrp_state(st)) return e;
     DGL_CHECK_ARG(length_out != nullptr, "length_out is NULL");
-    hipLaunchKernelGGL(cvrp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
+    if (dgl_sqrt_reference_bits())
+        hipLaunchKernelGGL(cvrp_length_torch_kernel, dim3((st->R + 7) / 8), dim3(256), 0, (hipStream_t)stream, *st, length_out, DglSqrtMkl{});
+    else
+        hipLaunchKernelGGL(cvrp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
     DGL_CHECK_LAUNCH("dgl_cvrp_route_length");
     return DGL_OK;
 }

@@ -100,6 +100,42 @@ __device__ __forceinline__ void dgl_reset_rows(const float *__restrict__ xy, con
     }
 }
 
+// torch's float sum over the last dimension of a contiguous matrix, for one row of M elements, by the 32 lanes of half a
+// wave (lane (k, v) = accumulator k, vector lane v): ATen's cascade sum as described at dgl_reset_rows_torch below, which
+// interleaves its binary64 sums with the same loops; here for the tour lengths (TSP/TSPEnv.py:560-562,
+// CVRP/CVRPEnv.py:991).  value(j, std::true_type) is called by all 64 lanes of the wave together (a model's wave-wide
+// root may be taken there), value(j, std::false_type) under a lane mask.  The row's sum is returned on every lane.
+template <class F>
+__device__ __forceinline__ float dgl_torch_row_sum(int M, F value) {
+    const std::true_type together{};
+    const std::false_type alone{};
+    const int l = threadIdx.x & 31, k = l >> 3, v = l & 7;
+    const int vec_size = M / 8, size_ilp = vec_size / 4;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;          // cascade levels
+    int t = 0;
+    while (t + 16 <= size_ilp) {
+        for (int u = 0; u < 16; ++u, ++t) a0 = __fadd_rn(a0, value(32 * t + l, together));
+        a1 = __fadd_rn(a1, a0); a0 = 0.0f;
+        if ((t & (15 << 4)) == 0) {
+            a2 = __fadd_rn(a2, a1); a1 = 0.0f;
+            if ((t & (15 << 8)) == 0) { a3 = __fadd_rn(a3, a2); a2 = 0.0f; }
+        }
+    }
+    for (; t < size_ilp; ++t) a0 = __fadd_rn(a0, value(32 * t + l, together));
+    a0 = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+    for (int w = 4 * size_ilp; w < vec_size; ++w)              // left-over vectors: accumulator 0 only
+        if (k == 0) a0 = __fadd_rn(a0, value(8 * w + v, alone));
+    const int base = threadIdx.x & 32;                         // first lane of this half of the wave
+    float p0 = a0;                                             // accumulators 1, 2, 3 into accumulator 0, in that order
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk) p0 = __fadd_rn(p0, __shfl(a0, base + 8 * kk + v, 64));
+    float total = 0.0f;                                        // scalar tail, then the eight lanes in order
+    for (int j = 8 * vec_size; j < M; ++j) total = __fadd_rn(total, value(j, together));
+#pragma unroll
+    for (int vv = 0; vv < 8; ++vv) total = __fadd_rn(total, __shfl(p0, base + vv, 64));
+    return total;
+}
+
 // The same reset with torch's own arithmetic for the row means, for the square-root models that aim at the reference's
 // bits (DglSqrtMkl): torch.mean over the last dimension of a contiguous float matrix is ATen's cascade sum
 // (aten/src/ATen/native/cpu/SumKernel.cpp) with 8-lane vectors, whatever the CPU: a row of M floats is read as

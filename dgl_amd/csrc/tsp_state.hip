@@ -57,7 +57,8 @@ __global__ void tsp_state_data_kernel(dgl_tsp_state_t st, int t, float *__restri
 }
 
 // --------------------------------------------------------------------- tour length
-// one wave per row; segment = sqrt(fl(dx^2) + fl(dy^2)) as TSP/TSPEnv.py:559-560
+// one wave per row; segment = sqrt(fl(dx^2) + fl(dy^2)) as TSP/TSPEnv.py:559-560, correctly rounded roots, the sum in
+// binary64 rounded once
 __global__ __launch_bounds__(256) void tsp_length_kernel(dgl_tsp_state_t st, float *__restrict__ out) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= st.R) return;
@@ -72,6 +73,24 @@ __global__ __launch_bounds__(256) void tsp_length_kernel(dgl_tsp_state_t st, flo
     }
     s = wave_sum_f64(s);
     if (lane == 0) out[r] = (float)s;
+}
+
+// The same length as the reference's torch build returns it: every segment's root through the reference-bits model (a
+// .sqrt() over a contiguous tensor, whatever the instance's size), summed over the tour in torch.sum's order
+// (dgl_torch_row_sum).  Half a wave per row; rows past the end repeat the last one and store nothing.
+__global__ __launch_bounds__(256) void tsp_length_torch_kernel(dgl_tsp_state_t st, float *__restrict__ out, DglSqrtMkl sq) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), r = min(row, st.R - 1);
+    const int N = st.N;
+    const float *xyb = st.xy + (size_t)(r / st.rows_per_instance) * N * 2;
+    const int32_t *tour = st.tour + (size_t)r * N;
+    const DglSqrtMkl::Lanes ln = sq.lanes();
+    const float total = dgl_torch_row_sum(N, [&](int p, auto all_lanes) {
+        const int a = min(max(tour[p], 0), N - 1), c = min(max(tour[p + 1 == N ? 0 : p + 1], 0), N - 1);
+        const float dx = __fsub_rn(xyb[2 * a], xyb[2 * c]), dy = __fsub_rn(xyb[2 * a + 1], xyb[2 * c + 1]);
+        const float r2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        return decltype(all_lanes)::value ? sq.all(ln, r2) : sq(r2);
+    });
+    if (row < st.R && (threadIdx.x & 31) == 0) out[row] = total;
 }
 
 // ------------------------------------------------------------------ beam permutation
@@ -309,7 +328,10 @@ extern "C" int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *d
 extern "C" int dgl_tsp_tour_length(const dgl_tsp_state_t *st, float *length_out, dgl_stream_t stream) {
     if (int e = check_tsp_state(st)) return e;
     DGL_CHECK_ARG(length_out != nullptr, "length_out is NULL");
-    hipLaunchKernelGGL(tsp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
+    if (dgl_sqrt_reference_bits())
+        hipLaunchKernelGGL(tsp_length_torch_kernel, dim3((st->R + 7) / 8), dim3(256), 0, (hipStream_t)stream, *st, length_out, DglSqrtMkl{});
+    else
+        hipLaunchKernelGGL(tsp_length_kernel, dim3((st->R + 3) / 4), dim3(256), 0, (hipStream_t)stream, *st, length_out);
     DGL_CHECK_LAUNCH("dgl_tsp_tour_length");
     return DGL_OK;
 }

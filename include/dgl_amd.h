@@ -72,6 +72,7 @@ DGL_API const char *dgl_last_error_string(void);
  *   DGL_SQRT_IEEE        correctly rounded roots (what torch without MKL, or on another CPU path, computes up to its
  *                        own library's rounding); the reset's means are binary64 sums rounded once.  Step kernels up
  *                        to 4 % faster at saturating batches, rollouts about 1 %.
+ * The model also decides how tour lengths are rounded (dgl_tsp_tour_length, dgl_cvrp_route_length).
  * The setting is per device (the current one) and process-wide; set it before the reset of the states it should apply to.
  * The Python host (dgl_amd/sqrt_model.py) sets it on every device it creates an engine on (environment: DGL_SQRT_MODEL=ieee
  * or mkl_avx512).  dgl_tsp_greedy_decode implements DGL_SQRT_IEEE only and refuses to run under the other model. */
@@ -141,8 +142,9 @@ DGL_API int dgl_tsp_knn(const dgl_tsp_state_t *st, int32_t t, int32_t knn, int32
  * materialised from the compact state after t >= 1 steps; for API parity and tests. */
 DGL_API int dgl_tsp_state_data(const dgl_tsp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
 
-/* TSPEnv._get_travel_distance (TSP/TSPEnv.py:554-564): closed tour length per row,
- * segments sqrt(fl(dx^2)+fl(dy^2)), accumulated in binary64, rounded once. */
+/* TSPEnv._get_travel_distance (TSP/TSPEnv.py:554-564): closed tour length per row, segments sqrt(fl(dx^2)+fl(dy^2)).
+ * Under DGL_SQRT_MKL_AVX512 the float the reference's torch build returns: its roots, summed in torch.sum's order
+ * (binary32 cascade sum); under DGL_SQRT_IEEE correctly rounded roots accumulated in binary64 and rounded once. */
 DGL_API int dgl_tsp_tour_length(const dgl_tsp_state_t *st, float *length_out, dgl_stream_t stream);
 
 /* ----------------------------------------------------------------- CVRP state
@@ -202,7 +204,7 @@ DGL_API int dgl_cvrp_knn(const dgl_cvrp_state_t *st, int32_t t, int32_t knn, int
 /* step_state.data [R][M][8] (CVRP/CVRPEnv.py:696,718,746,782,801). */
 DGL_API int dgl_cvrp_state_data(const dgl_cvrp_state_t *st, int32_t t, float *data_out, dgl_stream_t stream);
 
-/* CVRPEnv.cal_length (CVRP/CVRPEnv.py:951-993). */
+/* CVRPEnv.cal_length (CVRP/CVRPEnv.py:951-993); roots and summation per square-root model as dgl_tsp_tour_length. */
 DGL_API int dgl_cvrp_route_length(const dgl_cvrp_state_t *st, float *length_out, dgl_stream_t stream);
 
 /* --------------------------------------------------------------------- policy
