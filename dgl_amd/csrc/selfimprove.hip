@@ -4,6 +4,7 @@
 // runs these as host loops over a dense distance matrix; here one workgroup owns an instance and
 // keeps its coordinates in LDS.
 #include "common.h"
+#include "state_common.h"
 
 namespace {
 
@@ -23,18 +24,23 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // distances go to the lower index.  M nodes per instance; CVRP: node 0 is the depot and never
 // chosen, a move goes via the depot (flag 1, capacity refilled) when the load does not fit
 // (capacity + 1e-6 < demand), the first move always does.
-// dynamic LDS: float2 pts[M], float nrm[M] (|p|^2, -1 once visited).
+// dynamic LDS: float2 pts[M], float nrm[M] (|p|^2, -1 once visited), float edge[M] (TSP under torch's summation).
 // M <= DGL_DIRECT_MAX_POINTS: cdist's direct evaluation (common.h, dgl_direct_sq); nrm then only marks the visited.
-template <bool CVRP>
+// SQ: the square-root model of the matrix entries (common.h).  Under the reference-bits model the TSP label's length is
+// torch.sum's float over the chosen entries in tour order (TSP/TSPEnv.py:167: dgl_torch_row_sum), else their binary64
+// sum rounded once.
+template <bool CVRP, class SQ>
 __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const float *__restrict__ xy,
                                                                        const float *__restrict__ demand, int M,
                                                                        int32_t *__restrict__ nodes,
                                                                        int8_t *__restrict__ flags,
-                                                                       float *__restrict__ length) {
+                                                                       float *__restrict__ length, SQ sq) {
+    constexpr bool TORCH_SUM = SQ::WAVE_WIDE;                  // (the reference-bits model)
     extern __shared__ float lds[];
     __shared__ unsigned long long red[2][NN_THREADS / 64];
     float2 *pts = reinterpret_cast<float2 *>(lds);
     float *nrm = lds + 2 * (size_t)M;
+    float *edge = nrm + M;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float2 *in = reinterpret_cast<const float2 *>(xy) + (size_t)b * M;
     const bool direct = M <= DGL_DIRECT_MAX_POINTS;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const flo
             if (nj < 0.0f) continue;
             const float2 pj = pts[j];
             const float d = direct ? dgl_sqrt(dgl_direct_sq(pc.x, pc.y, pj.x, pj.y))
-                                   : dgl_chain_dist(pc.x, pc.y, nc, pj.x, pj.y, nj);
+                                   : sq(dgl_chain_sq(dgl_chain_cross(pc.x, pc.y, pj.x, pj.y), nc, nj));
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
             best = key < best ? key : best;
         }
@@ -89,14 +95,28 @@ __global__ __launch_bounds__(NN_THREADS) void nearest_neighbour_kernel(const flo
             }
         } else {
             total += (double)__uint_as_float((unsigned)(best >> 32));
-            if (tid == 0) out[pos] = j;
+            if (tid == 0) {
+                out[pos] = j;
+                if (TORCH_SUM) edge[pos - 1] = __uint_as_float((unsigned)(best >> 32));
+            }
         }
         cur = j;
     }
-    if (!CVRP && tid == 0) {
+    if (!CVRP) {
         const float2 pc = pts[cur], p0 = pts[0];               // closing edge: row = last node, column = node 0
-        total += (double)dgl_pair_dist(direct, pc.x, pc.y, p0.x, p0.y);
-        length[b] = (float)total;
+        const float closing = direct ? dgl_sqrt(dgl_direct_sq(pc.x, pc.y, p0.x, p0.y))
+                                     : sq(dgl_chain_sq(dgl_chain_cross(pc.x, pc.y, p0.x, p0.y), dgl_sqnorm(pc.x, pc.y),
+                                                       dgl_sqnorm(p0.x, p0.y)));
+        if (!TORCH_SUM) {
+            if (tid == 0) length[b] = (float)(total + (double)closing);
+        } else {
+            if (tid == 0) edge[M - 1] = closing;
+            __syncthreads();
+            if (tid < 64) {                                    // (both halves of the wave sum the same row)
+                const float sum = dgl_torch_row_sum(M, [&](int p, auto) { return edge[p]; });
+                if (tid == 0) length[b] = sum;
+            }
+        }
     }
 }
 
@@ -167,11 +187,17 @@ __global__ __launch_bounds__(256) void solution_augment_kernel(const int32_t *__
 extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, int32_t *solution, float *length,
                                          dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && solution && length && B > 0 && N > 1, "bad argument");
-    const size_t lds = (size_t)N * 12;
-    DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
-    dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<false>), (int)lds);
-    hipLaunchKernelGGL(nearest_neighbour_kernel<false>, dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy,
-                       (const float *)nullptr, N, solution, (int8_t *)nullptr, length);
+    const size_t lds = (size_t)N * 16;
+    DGL_CHECK_ARG(lds <= 150 * 1024, "more than 9600 nodes per instance do not fit the workgroup's LDS");
+    if (dgl_sqrt_reference_bits()) {
+        dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<false, DglSqrtMkl>), (int)lds);
+        hipLaunchKernelGGL((nearest_neighbour_kernel<false, DglSqrtMkl>), dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy,
+                           (const float *)nullptr, N, solution, (int8_t *)nullptr, length, DglSqrtMkl{});
+    } else {
+        dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<false, DglSqrtIeee>), (int)lds);
+        hipLaunchKernelGGL((nearest_neighbour_kernel<false, DglSqrtIeee>), dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy,
+                           (const float *)nullptr, N, solution, (int8_t *)nullptr, length, DglSqrtIeee{});
+    }
     DGL_CHECK_LAUNCH("dgl_tsp_nearest_neighbour");
     return DGL_OK;
 }
@@ -179,11 +205,17 @@ extern "C" int dgl_tsp_nearest_neighbour(const float *xy, int32_t B, int32_t N, 
 extern "C" int dgl_cvrp_nearest_neighbour(const float *xy, const float *demand, int32_t B, int32_t N, int32_t *nodes,
                                           int8_t *flags, dgl_stream_t stream) {
     DGL_CHECK_ARG(xy && demand && nodes && flags && B > 0 && N > 0, "bad argument");
-    const size_t lds = (size_t)(N + 1) * 12;
-    DGL_CHECK_ARG(lds <= 150 * 1024, "more than 12800 nodes per instance do not fit the workgroup's LDS");
-    dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<true>), (int)lds);
-    hipLaunchKernelGGL(nearest_neighbour_kernel<true>, dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy, demand,
-                       N + 1, nodes, flags, (float *)nullptr);
+    const size_t lds = (size_t)(N + 1) * 16;
+    DGL_CHECK_ARG(lds <= 150 * 1024, "more than 9600 nodes per instance do not fit the workgroup's LDS");
+    if (dgl_sqrt_reference_bits()) {
+        dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<true, DglSqrtMkl>), (int)lds);
+        hipLaunchKernelGGL((nearest_neighbour_kernel<true, DglSqrtMkl>), dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy, demand,
+                           N + 1, nodes, flags, (float *)nullptr, DglSqrtMkl{});
+    } else {
+        dgl_max_dynamic_lds(reinterpret_cast<const void *>(nearest_neighbour_kernel<true, DglSqrtIeee>), (int)lds);
+        hipLaunchKernelGGL((nearest_neighbour_kernel<true, DglSqrtIeee>), dim3(B), dim3(NN_THREADS), lds, (hipStream_t)stream, xy, demand,
+                           N + 1, nodes, flags, (float *)nullptr, DglSqrtIeee{});
+    }
     DGL_CHECK_LAUNCH("dgl_cvrp_nearest_neighbour");
     return DGL_OK;
 }

@@ -372,7 +372,9 @@ DGL_API int dgl_augment(const float *xy, int32_t B, int32_t M, const float *cos_
  * Nearest-neighbour construction the trainers start from.  TSP (TSPEnv.greedy_search,
  * TSP/TSPEnv.py:140-169): from node 0 always to the nearest unvisited node by the entries of the
  * reference's cdist matrix (row = current node; equal distances go to the lower index);
- * solution [B][N] int32, length [B] = sum of those entries around the closed tour.
+ * solution [B][N] int32, length [B] = sum of those entries around the closed tour.  The entries' roots follow the
+ * square-root model (dgl_set_sqrt_model); under DGL_SQRT_MKL_AVX512 the sum is torch.sum's float (TSP/TSPEnv.py:167),
+ * under DGL_SQRT_IEEE a binary64 sum rounded once.  At most 9600 nodes per instance (the workgroup's LDS).
  * CVRP (CVRPEnv.greedy_search, CVRP/CVRPEnv.py:340-409): from the depot to the nearest unvisited
  * customer; a move goes via the depot (flag 1, capacity 1 - demand) when capacity + 1e-6 < demand,
  * the first move always does.  xy [B][N+1][2], demand [B][N+1]; nodes [B][N] int32, flags [B][N]
