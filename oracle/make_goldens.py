@@ -372,6 +372,9 @@ TRAINED_CASES = {
     "tsp_n10000_b2_nn_tours": ("tsp", dict(seed=10000, B=2, N=10000, knn=30, light="tours16")),
     # configuration 4 as the reference runs it (TSP/test.py:126-129): one TSP-10000 instance, beam 16, with the beam trace
     "tsp_n10000_b1_beam16_nn": ("tsp", dict(seed=10016, B=1, N=10000, knn=30, beam=16, light="tours")),
+    # beam decoding at the headline size, two instances each
+    "tsp_n1000_b2_beam16_nn": ("tsp", dict(seed=1016, B=2, N=1000, knn=30, beam=16, light="tours")),
+    "cvrp_n1000_b2_beam16_nn": ("cvrp", dict(seed=1016, B=2, N=1000, knn=15, depot_knn=15, beam=16, light="tours")),
     # configuration 5's size and neighbourhoods (CVRP/train.py:130-131: knn = depot_knn = 100, 202 tokens per row)
     "cvrp_n5000_b2_k100_nn_tours": ("cvrp", dict(seed=5000, B=2, N=5000, knn=100, depot_knn=100, light="tours16")),
     # at most 25 points per instance: torch.cdist evaluates the distances pair by pair instead of through a matrix

@@ -38,6 +38,7 @@ def _setup(name, device):
                                   "cvrp_n60_b2_beam4_pomo2", "cvrp_n150_b2_beam8_nn",
                                   "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn",
                                   "tsp_n25_b2_beam4", "cvrp_n24_b2_beam4",
+                                  "tsp_n1000_b2_beam16_nn", "cvrp_n1000_b2_beam16_nn",     # the headline size
                                   "tsp_n10000_b1_beam16_nn"])      # configuration 4 as the reference runs it: 9 999 expansions
 def test_teacher_forced_beam_steps(name, device):
     """At every step: dense and compact kernels agree with each other and with the reference's
@@ -105,7 +106,7 @@ def test_teacher_forced_beam_steps(name, device):
 
 @pytest.mark.parametrize("name", ["tsp_n200_b2_beam8_nn", "cvrp_n150_b2_beam8_nn",
                                   "tsp_n150_b1_beam100_k100_nn", "cvrp_n100_b1_beam100_k100_nn",
-                                  "tsp_n10000_b1_beam16_nn"])
+                                  "tsp_n1000_b2_beam16_nn", "cvrp_n1000_b2_beam16_nn", "tsp_n10000_b1_beam16_nn"])
 def test_free_running_beam_rollout_trained(name, device):
     case, eng, pol, beam, A, start = _setup(name, device)
     length = eng.beam_rollout(pol, start, beam).cpu().numpy()
