@@ -41,6 +41,9 @@ def test_tsp_oracle_reproduces_reference(name):
         case = dict(case, xy=case["xy"][:m], tour=case["tour"][:m], length=case["length"][:m])
     if case["xy"].shape[1] >= 1000 and case["xy"].shape[0] > 4:
         pytest.skip("large case: covered by the GPU tests (keeps the CPU suite short)")
+    if case["xy"].shape[1] >= 10000 and int(case["meta/beam"]) > 1 and os.environ.get("DGL_LONG_TESTS", "0") != "1":
+        pytest.skip("TSP-10000 beam 16: 107 s of oracle time (passes; DGL_LONG_TESTS=1 runs it); the GPU tests compare the "
+                    "device with this capture directly")
     oracle = TSPOracle(weights, int(case["meta/knn"]))
     rec = []
     out = tsp_rollout(oracle, torch.from_numpy(case["xy"]), torch.from_numpy(case["start"]).long(),
