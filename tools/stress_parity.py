@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU (beyond the fixed cases of tests/): for a given number of seconds draws sizes at
 random and checks
-  * the TSP step kernel (state recurrences, neighbourhoods) against the plain-C oracle, bit for bit, N = 2 ... 3000,
-    knn = 1 ... 120, 1 ... 5 rows, whole tours for short instances and prefixes for long ones;
+  * the TSP step kernel (state recurrences, neighbourhoods) against the plain-C oracle, bit for bit, N = 2 ... 12000,
+    knn = 1 ... 256, 1 ... 5 rows, whole tours for short instances and prefixes for long ones;
   * the CVRP step kernel likewise (both neighbourhoods, capacities, feasibility);
   * the one-launch policy kernel for 33 ... 128 tokens against the general path, TSP and CVRP layouts.
 Every step-kernel case draws its square-root model too: correctly rounded roots, or the reference-bits model with the C
@@ -32,22 +32,23 @@ while time.time() - t0 < budget:
     kind = rng.choice(["tsp", "tsp", "cvrp", "wide_tsp", "wide_cvrp"])
     model = str(rng.choice(["ieee", "mkl_avx512"]))
     if kind == "tsp":
-        N = int(rng.choice([rng.integers(2, 27), rng.integers(26, 200), rng.integers(200, 1200), rng.integers(1200, 3000)]))
-        knn = int(rng.choice([1, 5, 15, 30, 31, 50, 64, 65, 100, 120]))
+        N = int(rng.choice([rng.integers(2, 27), rng.integers(26, 200), rng.integers(200, 1200), rng.integers(1200, 3000),
+                            rng.integers(3000, 12000)]))
+        knn = int(rng.choice([1, 5, 15, 30, 31, 50, 64, 65, 100, 120, 200, 256]))
         B = int(rng.integers(1, 6))
         xy = rng.random((B, N, 2), dtype=np.float32)
         if rng.random() < 0.2:                                   # duplicates: exact ties
             xy[:, N // 2:] = xy[:, :N - N // 2]
         order = np.stack([rng.permutation(N) for _ in range(B)])
-        until = None if N <= 300 else int(rng.integers(20, 80))
+        until = None if N <= 300 else int(rng.integers(20, 80)) if N <= 3000 else int(rng.integers(6, 16))
         try:
             K._run_case(dev, xy, order, knn, check_until=until, model=model)
         except AssertionError as e:
             print("TSP MISMATCH", dict(N=N, knn=knn, B=B, until=until, model=model), str(e)[:300], flush=True); raise
     elif kind == "cvrp":
-        N = int(rng.choice([rng.integers(2, 26), rng.integers(25, 200), rng.integers(200, 1500)]))
-        knn, kd = int(rng.choice([1, 8, 15, 30, 50, 100])), int(rng.choice([1, 8, 15, 30, 50, 100]))
-        until = None if N <= 200 else int(rng.integers(20, 60))
+        N = int(rng.choice([rng.integers(2, 26), rng.integers(25, 200), rng.integers(200, 1500), rng.integers(1500, 6000)]))
+        knn, kd = int(rng.choice([1, 8, 15, 30, 50, 100, 128])), int(rng.choice([1, 8, 15, 30, 50, 100, 128]))
+        until = None if N <= 200 else int(rng.integers(20, 60)) if N <= 1500 else int(rng.integers(6, 16))
         try:
             C._recurrences_vs_c_oracle(dev, N, knn, kd, until, seed=int(rng.integers(1 << 30)), B=int(rng.integers(1, 4)), model=model)
         except AssertionError as e:
