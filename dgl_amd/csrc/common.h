@@ -102,10 +102,18 @@ struct DglSqrtIeeeT {
     static constexpr unsigned ULPS = 4u;
     static constexpr bool DIRECT = DIRECT_;
     static constexpr bool WAVE_WIDE = false;    // no root needs the other lanes of its wave
+    static constexpr bool GROUPED = false;
     struct Lanes {};
     __device__ __forceinline__ Lanes lanes() const { return Lanes{}; }
     __device__ __forceinline__ float all(const Lanes &, float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float dist_all(const Lanes &, float x) const { return dgl_sqrt(x); }
+    template <int K>
+    __device__ __forceinline__ void all_n(const Lanes &, const float (&x)[K], float (&out)[K]) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = dgl_sqrt(x[k]);
+    }
+    template <int K>
+    __device__ __forceinline__ void dist_all_n(const Lanes &ln, const float (&x)[K], float (&out)[K]) const { all_n(ln, x, out); }
     __device__ __forceinline__ float operator()(float x) const { return dgl_sqrt(x); }
     __device__ __forceinline__ float pk(float x) const { return dgl_sqrt_pk(x); }
     __device__ __forceinline__ float dist(float x) const { return dgl_sqrt(x); }
@@ -137,10 +145,15 @@ static __constant__ int2 DGL_RSQRT14_SEG[64] = {
     {17174400, -437}, {16727424, -425}, {16292608, -415}, {15867648, -403},
     {15454080, -393}, {15051520, -385}, {14657408, -375}, {14273792, -367},
 };
-template <bool DIRECT_>
+// GROUPED: the scan loops take the roots of a whole group of node chunks together (all_n: one branch, the chunks'
+// dependent chains overlap) - 0.2-0.35 us less per launch where a launch is latency-bound, 1.5 % at a saturating batch
+// for TSP; the CVRP kernel at a saturating batch loses 12 % that way (96 registers instead of 70), so its launcher picks
+// the chunk-by-chunk form from 2048 rows on.
+template <bool DIRECT_, bool GROUPED_ = true>
 struct DglSqrtMklT {
     static constexpr unsigned ULPS = 8u;
     static constexpr bool DIRECT = DIRECT_;
+    static constexpr bool GROUPED = GROUPED_;
     // Where all 64 lanes of a wave are active (the scan loops, the candidates' feature rows) a root is taken with
     // all(ln, x) / dist_all(ln, x): every lane goes through the closed form, the segment constants fetched from the
     // lanes' registers (Lanes: lane l holds segment l) by ds_bpermute - no memory access, no filter.  ds_bpermute
@@ -182,6 +195,32 @@ struct DglSqrtMklT {
     }
     // (distance roots under DIRECT: the correctly rounded ones)
     __device__ __forceinline__ float dist_all(const Lanes &ln, float x) const { return DIRECT ? dgl_sqrt(x) : all(ln, x); }
+    // K independent roots behind one branch for the unusual inputs: their dependent chains (look-up, refinement) overlap
+    template <int K>
+    __device__ __forceinline__ void all_n(const Lanes &ln, const float (&x)[K], float (&out)[K]) const {
+        bool odd = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int addr = (int)((__float_as_uint(x[k]) >> 16) & 0xFCu);
+            const int c = __builtin_amdgcn_ds_bpermute(addr, ln.c), ns = __builtin_amdgcn_ds_bpermute(addr, ln.ns);
+            out[k] = refine(x[k], c, ns);
+            odd = odd || !ordinary(x[k]);
+        }
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (!ordinary(x[k])) out[k] = dgl_sqrt(x[k]);
+        }
+    }
+    template <int K>
+    __device__ __forceinline__ void dist_all_n(const Lanes &ln, const float (&x)[K], float (&out)[K]) const {
+        if (DIRECT) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = dgl_sqrt(x[k]);
+        } else {
+            all_n(ln, x, out);
+        }
+    }
     __device__ __forceinline__ float dist(float x) const { return DIRECT ? dgl_sqrt(x) : (*this)(x); }
     __device__ __forceinline__ float dist_pk(float x) const { return dist(x); }
     // one root under any lane mask: the correctly rounded root, replaced where MKL's result can differ from it.  Over all

@@ -189,12 +189,35 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(96))) vo
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        float a1g[STEP_UNROLL], s1g[STEP_UNROLL];
+        if constexpr (SQ::WAVE_WIDE && UPDATE && SQ::GROUPED) {
+            float rad[STEP_UNROLL], dcolg[STEP_UNROLL], item[STEP_UNROLL];
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                rad[q] = dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]),
+                                      cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]), cx.nc);
+            }
+            sq.dist_all_n(sq_lanes, rad, dcolg);
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float a0 = g.a0[q], s0 = g.s0[q], dcol = dcolg[q];
+                a1g[q] = dgl_div(__fsub_rn(__fmul_rn(a0, up1), dcol), du);                          // :711
+                const float e = __fsub_rn(dcol, a0);
+                const float it = dgl_div(__fsub_rn(__fmul_rn(__fmul_rn(s0, s0), up1), __fmul_rn(e, e)), du);   // :733
+                item[q] = it < 0.0f ? 0.0f : it;                                                    // :735-736
+            }
+            sq.all_n(sq_lanes, item, s1g);
+        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             // models with wave-wide roots (common.h): both roots by every lane, before the guard (the loads were clamped)
             float a1w = 0.0f, s1w = 0.0f;
-            if constexpr (SQ::WAVE_WIDE && UPDATE) {
+            if constexpr (SQ::WAVE_WIDE && UPDATE && SQ::GROUPED) {
+                a1w = a1g[q];
+                s1w = s1g[q];
+            } else if constexpr (SQ::WAVE_WIDE && UPDATE) {
                 const float x = g.p[q].x, y = g.p[q].y;
                 const float dcol = sq.dist_all(sq_lanes, dgl_chain_sq(cvrp_cross<D3, SQ::DIRECT>(cx.xc, cx.yc, cx.zc, x, y, g.dm[q]),
                                                                       cvrp_norm<D3, SQ::DIRECT>(x, y, g.dm[q]), cx.nc));
@@ -625,9 +648,13 @@ static int launch_cvrp_step(const dgl_cvrp_state_t *st, const int32_t *action, i
         return launch_cvrp_step_small<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                                   tile_out, stream, what, link, DglSqrtIeeeT<true>{});
     }
-    if (dgl_sqrt_reference_bits())
+    if (dgl_sqrt_reference_bits()) {
+        if (st->R >= 2048)                                     // (common.h, GROUPED: registers count where the batch saturates the card)
+            return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
+                                                   tile_out, stream, what, link, DglSqrtMklT<false, false>{});
         return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                                tile_out, stream, what, link, DglSqrtMkl{});
+    }
     return launch_cvrp_step_sq<UPDATE, D3>(st, action, t, knn, depot_knn, idx_last_out, idx_depot_out, infeasible_out,
                                            tile_out, stream, what, link, DglSqrtIeee{});
 }

@@ -147,12 +147,29 @@ __device__ __forceinline__ void tsp_step_row(const dgl_tsp_state_t &st, const in
         const Group g = nxt;
         if (j0 + 64 * STEP_UNROLL < j_end) request(j0 + 64 * STEP_UNROLL, nxt);
         if (want_knn && (j0 == j_begin || ((j0 >> 6) & 63) == 0)) vis_words = vis_in[min(((j0 >> 6) & ~63) + lane, W - 1)];
+        float a1g[STEP_UNROLL], s1g[STEP_UNROLL];
+        if constexpr (SQ::WAVE_WIDE && UPDATE && SQ::GROUPED) {
+            float rad[STEP_UNROLL], dcolg[STEP_UNROLL], item[STEP_UNROLL];
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q) {
+                const float x = g.p[q].x, y = g.p[q].y;
+                rad[q] = dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y), dgl_sqnorm_t<SQ::DIRECT>(x, y), cx.nc);
+            }
+            sq.dist_all_n(sq_lanes, rad, dcolg);
+#pragma unroll
+            for (int q = 0; q < STEP_UNROLL; ++q)
+                dgl_update_moments_item<false>(dcolg[q], g.a0[q], g.s0[q], up1, du, &a1g[q], &item[q]);
+            sq.all_n(sq_lanes, item, s1g);
+        }
 #pragma unroll
         for (int q = 0; q < STEP_UNROLL; ++q) {
             const int j = j0 + 64 * q + lane;
             // models with wave-wide roots (common.h): both roots by every lane, before the guard (the loads were clamped)
             float a1w = 0.0f, s1w = 0.0f;
-            if constexpr (SQ::WAVE_WIDE && UPDATE) {
+            if constexpr (SQ::WAVE_WIDE && UPDATE && SQ::GROUPED) {
+                a1w = a1g[q];
+                s1w = s1g[q];
+            } else if constexpr (SQ::WAVE_WIDE && UPDATE) {
                 const float x = g.p[q].x, y = g.p[q].y;
                 const float dcol = sq.dist_all(sq_lanes, dgl_chain_sq(dgl_cross_t<SQ::DIRECT>(cx.xc, cx.yc, x, y),
                                                                       dgl_sqnorm_t<SQ::DIRECT>(x, y), cx.nc));
